@@ -1,0 +1,165 @@
+/*
+ * rt_mi355x.h -- C ABI of librt_mi355x.so, the MI355X (gfx950) implementation of the
+ * RayTracer2 propagation loop.
+ *
+ * The reference (cericdahl/RayTracer) has no FFI: its boundary is the Python function
+ *   RayTracer2(ray_startingpoints, rays, surfacelist, max_scat, min_travel_len, follow_thresh,
+ *              tir_handling, full_output, singlechild, output_raytable)
+ * (python/RayTracer2.py:185, MATLAB/RayTracer2.m:177).  This header is what a ctypes/cffi binding of
+ * that function calls; raytracer_amd/RayTracer2.py is such a binding and keeps the reference signature.
+ *
+ * Everything is plain C: pointers + sizes, int return codes (0 = ok, <0 = error, text from
+ * rt_last_error()).  No exception crosses this boundary.  Host buffers are owned by the caller; device
+ * buffers are owned by the context (or borrowed, see rt_trace_device).
+ *
+ * ---------------------------------------------------------------------------------------------
+ * Data formats (shared with the CPU oracle in oracle/, which re-implements the readers on its own)
+ * ---------------------------------------------------------------------------------------------
+ * Surface table: n_surf rows of RT_ROW doubles, one row per `surface` object
+ * (python/surface.py:51-62 + optional attributes python/RayTracer2.py:232-248):
+ *   [0]      shape id        RT_SHAPE_*     (python/RayToShape.py:18-29)
+ *   [1]      surface type id RT_STYPE_*     (python/RayTracer2.py:301-309; anything else = normal)
+ *   [2..14]  geometry parameters, meaning depends on shape:
+ *              plane       point(3) normal(3)            (RayToPlane.py:5, normal normalised :27-28)
+ *              sphere      center(3) radius              (RayToSphere.py:18)
+ *              cylinder    center(3) axis(3) radius      (RayToCylinder.py:53, axis normalised :73-74)
+ *              quadsurface Q(9, row-major) P(3) R        (MATLAB/RayToX/RayToQuadsurface.m:55)
+ *              torus       center(3) axis(3) r1 r2       (MATLAB/RayToX/RayToTorus.m:50, axis normalised :75-76)
+ *   [15] n_outside  [16] n_inside  [17] absorption
+ *   [18] abslength_outside [19] abslength_inside [20] rayleigh_outside [21] rayleigh_inside
+ *   [22..26] unifiedparams[5] = {sigma_alpha, P_diffuse_reemit, P_lobe, P_spike, P_back}
+ *              (python/UnifiedReflectorModel.py:95, MATLAB/Physics/UnifiedReflectorModel.m:48)
+ *   [27] bounds program offset (index into code[]) [28] bounds program length  [29..31] reserved (0)
+ *
+ * Bounds program: the reference's `inbounds_function` is an opaque callable p(N,3,M) -> bool(N,M)
+ * (python/surface.py:19-32).  The host compiles it to a postfix boolean program over "atoms"; the
+ * program is evaluated per candidate hit point with a bit-stack (depth <= 32).
+ *   code[i] = (op << 24) | arg ;  ops RT_BOP_*
+ *   atom a  = atoms[a*RT_ATOM .. a*RT_ATOM+11] = {kind, cmp, rhs, c0..c8}
+ *     kind RT_ATOM_QUAD : v = c0 x^2 + c1 y^2 + c2 z^2 + c3 xy + c4 xz + c5 yz + c6 x + c7 y + c8 z
+ *     kind RT_ATOM_LIN  : v = c6 x + c7 y + c8 z
+ *     kind RT_ATOM_COORD: v = p[(int)c0]                                     (bit-exact `p[:,k,:] < c`)
+ *     kind RT_ATOM_ATAN2: v = atan2(c0 x + c1 y + c2 z + c3, c4 x + c5 y + c6 z + c7)
+ *     result = v <cmp> rhs, cmp in RT_CMP_* ; comparisons with NaN are false (NE: true), as in numpy.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ROW 32
+#define RT_ATOM 12
+#define RT_MAX_SURF 256
+
+enum { RT_SHAPE_PLANE = 0, RT_SHAPE_SPHERE = 1, RT_SHAPE_CYLINDER = 2, RT_SHAPE_QUADSURFACE = 3, RT_SHAPE_TORUS = 4 };
+enum { RT_STYPE_NORMAL = 0, RT_STYPE_DIFFUSE = 1, RT_STYPE_UNIFIED = 2, RT_STYPE_RETRO = 3 };
+enum { RT_BOP_ATOM = 1, RT_BOP_AND = 2, RT_BOP_OR = 3, RT_BOP_NOT = 4, RT_BOP_TRUE = 5, RT_BOP_FALSE = 6, RT_BOP_XOR = 7 };
+enum { RT_ATOM_QUAD = 0, RT_ATOM_LIN = 1, RT_ATOM_ATAN2 = 2, RT_ATOM_COORD = 3 };
+enum { RT_CMP_LT = 0, RT_CMP_LE = 1, RT_CMP_GT = 2, RT_CMP_GE = 3, RT_CMP_EQ = 4, RT_CMP_NE = 5 };
+
+/* row offsets */
+enum {
+    RT_R_SHAPE = 0, RT_R_STYPE = 1, RT_R_GEOM = 2, RT_R_NOUT = 15, RT_R_NIN = 16, RT_R_ABS = 17,
+    RT_R_ABSL_OUT = 18, RT_R_ABSL_IN = 19, RT_R_RAYL_OUT = 20, RT_R_RAYL_IN = 21, RT_R_UNIFIED = 22,
+    RT_R_BOFF = 27, RT_R_BLEN = 28
+};
+
+/* compat bits: which conventions/quirks of the numpy port are reproduced (SURVEY.md quirk ledger) */
+enum {
+    RT_COMPAT_PY_INDEX = 1, /* Q1/Q2/Q4/Q5: 0-based `n*orientation` indices; surface 0 loses its sign and is
+                               tallied on both orientations (python/RayTracer2.py:371,475-476); default */
+    RT_COMPAT_PY_ROOT2 = 2  /* Q16: second sphere/cylinder root = -(first) (python/RayToSphere.py:47) */
+};
+
+/* flags */
+enum {
+    RT_FLAG_FULL_OUTPUT = 1, /* keep one record per interaction (python/RayTracer2.py:489-507) */
+    RT_FLAG_SINGLECHILD = 2, /* dice between reflected/refracted child (python/RayTracer2.py:458-467) */
+    RT_FLAG_FINAL_ROWS = 4   /* keep the per-ray final row (see RT_FINAL_COLS) */
+};
+
+typedef struct rt_params {
+    int32_t max_scatters;    /* K      (RayTracer2.py:209-212) */
+    int32_t flags;           /* RT_FLAG_* */
+    int32_t compat;          /* RT_COMPAT_* */
+    int32_t unified_maxiter; /* cap of the UNIFIED rejection loops (reference: unbounded); 0 = default 10000 */
+    double min_travel_length; /* (RayTracer2.py:203-206) */
+    double follow_threshold[2]; /* refracted, reflected (RayTracer2.py:194-200, 518-519) */
+    double tir_handling;     /* <0: tangent ray with zero intensity; >=0: copy of reflected * value
+                                (RefractionReflectionAtInterface.m:217-225) */
+    uint64_t seed;           /* Philox key */
+    int64_t ray_id_base;     /* global id of ray 0 of this call (sharding over GPUs / chunks) */
+} rt_params;
+
+/* One record per interaction = one row of the reference's rayInterfaces arrays (python/rayInterfaces.py:4-20),
+ * RT_REC_COLS doubles:
+ *  [0..9] incoming_ray [10..19] refracted_ray [20..29] reflected_ray [30..32] intersection_point
+ *  [33..35] surface_normal (mechanical) [36] ray_index [37] surface_index [38] distance_traveled
+ *  [39] n_incident [40] n_transmitted [41] bulkabs_incident [42] bulkabs_transmitted
+ *  [43] rayleigh_incident [44] rayleigh_transmitted
+ *  extras (not in the reference): [45] orientation (+1 into / -1 out of the surface) [46] 0-based surface number
+ *  [47] 1 if Rayleigh scatter else 0 */
+#define RT_REC_COLS 48
+
+/* Final row per initial ray (the reduction python/BubbleImageCreator.py:149-161 + finalRays.py makes from
+ * ray_interfaces: last record of each ray id), RT_FINAL_COLS doubles:
+ *  [0..2] position of last interaction (start point if none) [3..5] direction [6..8] polref [9..12] Stokes s0..s3
+ *  of the ray arriving there, [13..15] surface normal, [16] surface_index (reference convention) [17] orientation
+ *  [18] ray_index [19] number of interactions [20] s0 still followed after it
+ *  [21] status: 0 escaped geometry, 1 absorbed / below threshold, 2 max_scatters reached, 3 none (never hit)
+ *  [22..23] reserved.  Non-dice mode: rows describe the never-reflected (positive ray_index) lineage. */
+#define RT_FINAL_COLS 24
+
+typedef struct rt_ctx rt_ctx;
+
+/* Create a context on HIP device `device`.  Replaces nothing in the reference (it has no device). */
+int rt_init(int device, rt_ctx** out);
+void rt_free(rt_ctx* ctx);
+const char* rt_last_error(rt_ctx* ctx); /* ctx may be NULL: last error of rt_init */
+
+/* Upload the geometry.  Replaces the per-call walk over `surfacelist` objects (RayTracer2.py:234-248, 288-374). */
+int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
+                    const double* atoms, int32_t n_atoms, const uint32_t* code, int32_t n_code);
+
+/* Upload the Rayleigh azimuth inverse-CDF table (MATLAB/Physics/RayleighScattering.m:55-60), n = precision+1. */
+int rt_set_rayleigh_lut(rt_ctx* ctx, const double* lut, int32_t n);
+
+/* Trace n rays given in the reference's host layout: start[n][3], rays[n][10] row-major
+ * (RayTracer2.py:185 arguments 1-2).  Blocking.  Results are fetched with rt_result_*. */
+int rt_trace(rt_ctx* ctx, const double* start, const double* rays, int64_t n, const rt_params* prm);
+
+/* Same, rays already resident in HBM as structure-of-arrays: d_soa[f*n + i], f = 0..2 start point,
+ * 3..12 the ten ray columns.  The pointer is a device pointer (e.g. torch tensor.data_ptr()). */
+int rt_trace_device(rt_ctx* ctx, const double* d_soa, int64_t n, const rt_params* prm);
+
+/* Generate n isotropic unpolarised unit-intensity rays from one point directly in HBM (the source of
+ * MATLAB/Examples/RunExamples/RunSBCGeometry.m:45-68) and trace them; no host arrays involved. */
+int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm);
+
+/* Launch-only variants for benchmarking: enqueue on the context's stream, do not wait. */
+int rt_trace_point_source_async(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm);
+int rt_sync(rt_ctx* ctx);
+
+/* Results of the last trace. */
+int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps);           /* rows of absorption_table (RayTracer2.py:542) */
+int rt_result_table(rt_ctx* ctx, double* table /* [num_steps][5][n_surf][2] */);
+int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live /*[K]*/, int64_t* n_scat /*[K]*/);
+int rt_result_num_records(rt_ctx* ctx, int64_t* n);
+/* records in device order + ordering metadata; the host wrapper sorts them into the reference's order */
+int rt_result_records(rt_ctx* ctx, double* rec /*[n][RT_REC_COLS]*/, int32_t* step /*[n]*/,
+                      int64_t* ray_id /*[n]*/, int64_t* parent /*[n]*/, int32_t* flags /*[n]*/);
+int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);
+/* kernel time of the last trace measured with HIP events on the context's stream, and launch count */
+int rt_result_timing(rt_ctx* ctx, double* kernel_ms, int32_t* n_launches);
+
+/* device properties the host side needs (CU count etc.) */
+int rt_device_info(rt_ctx* ctx, int32_t* n_cu, int64_t* hbm_bytes, char* name, int32_t name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

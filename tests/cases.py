@@ -1,0 +1,144 @@
+"""Seeded test geometries / ray sets shared by the golden generator and the tests.
+
+Geometries are the ones of the reference's own demo scripts (python/TestGeometry.py:41-106,
+python/SphereTest.py:20-31, python/UnifiedTest.py:12-37) plus SURVEY.md section 8d's config 1.
+`cls` is the surface class to instantiate: the reference's `surface.surface` when generating goldens,
+anything attribute-bag-like otherwise.
+"""
+import types
+
+import numpy as np
+
+
+class Surf(object):
+    """attribute bag with the fields of python/surface.py:51-62"""
+
+    def __init__(self):
+        self.description = None
+        self.n_outside = None
+        self.n_inside = None
+        self.surface_type = None
+        self.absorption = None
+        self.shape = None
+        self.param_list = None
+        self.inbounds_function = None
+
+
+def isotropic_rays(n, seed, origin=(0.0, 0.0, 0.0), polarized=False):
+    rng = np.random.default_rng(seed)
+    mu = rng.uniform(-1, 1, n)
+    ph = rng.uniform(0, 2 * np.pi, n)
+    st = np.sqrt(1 - mu * mu)
+    rays = np.zeros((n, 10))
+    rays[:, 0] = st * np.cos(ph); rays[:, 1] = st * np.sin(ph); rays[:, 2] = mu
+    rays[:, 3] = 1.0
+    # avoid a polref parallel to the direction
+    bad = np.abs(rays[:, 0]) > 0.999
+    rays[bad, 3] = 0; rays[bad, 4] = 1
+    rays[:, 6] = 1.0
+    if polarized:
+        pol = rng.uniform(-1, 1, (n, 3)) * 0.55
+        rays[:, 7:10] = pol
+    sp = np.tile(np.asarray(origin, float), (n, 1))
+    return sp, rays
+
+
+def sphere_plane(cls=Surf):
+    """dielectric sphere (n 1.5 inside) + absorbing plane below it."""
+    s = cls()
+    s.description = 'sphere R=10 n_in 1.5'
+    s.shape = 'sphere'; s.param_list = [np.array([0, 0, 0]), 10]
+    s.inbounds_function = lambda p: np.reshape((p[:, 2, :] >= -10) * (p[:, 2, :] <= 10), (p.shape[0], -1))
+    s.n_outside = 1.0; s.n_inside = 1.5; s.surface_type = 'normal'; s.absorption = 0
+    pl = cls()
+    pl.description = 'absorbing plane z=-20'
+    pl.shape = 'plane'; pl.param_list = [np.array([0, 0, -20]), np.array([0, 0, 1])]
+    pl.inbounds_function = lambda p: np.reshape((p[:, 0] ** 2 + p[:, 1] ** 2) < 10000, (p.shape[0], -1))
+    pl.n_outside = 1.0; pl.n_inside = np.inf; pl.surface_type = 'normal'; pl.absorption = 1
+    return [s, pl]
+
+
+def testgeometry(cls=Surf, cyl_type='unified', cyl_params=(0, 0, 0, 0, 0)):
+    """python/TestGeometry.py:41-106 (two-cell cylinder).  cyl_type='normal' gives a deterministic variant."""
+    sl = []
+    a = cls(); a.description = 'bottom cylinder'; a.shape = 'cylinder'
+    a.param_list = [np.array([0, 0, 0]), np.array([0, 0, 1]), 10]
+    a.inbounds_function = lambda p: np.reshape((p[:, 2, :] > 0) * (p[:, 2, :] < 5), (p.shape[0], -1))
+    a.n_outside = 1.5; a.n_inside = 1.5; a.surface_type = cyl_type; a.absorption = 0
+    b = cls(); b.description = 'top cylinder'; b.shape = 'cylinder'
+    b.param_list = [np.array([0, 0, 0]), np.array([0, 0, 1]), 10]
+    b.inbounds_function = lambda p: np.reshape((p[:, 2, :] >= 5) * (p[:, 2, :] < 10), (p.shape[0], -1))
+    b.n_outside = 1.5; b.n_inside = 2; b.surface_type = cyl_type; b.absorption = 0
+    if cyl_type == 'unified':
+        a.unifiedparams = list(cyl_params); b.unifiedparams = list(cyl_params)
+    if cyl_type == 'normal':
+        a.n_outside = 1.0; b.n_outside = 1.0
+    c = cls(); c.description = 'top cap'; c.shape = 'plane'
+    c.param_list = [np.array([0, 0, 10]), np.array([0, 0, 1])]
+    c.inbounds_function = lambda p: np.reshape((p[:, 0] ** 2 + p[:, 1] ** 2) < 100, (p.shape[0], -1))
+    c.n_outside = 1.5; c.n_inside = 2; c.surface_type = 'normal'; c.absorption = 1
+    d = cls(); d.description = 'mid disk'; d.shape = 'plane'
+    d.param_list = [np.array([0, 0, 5]), np.array([0, 0, 1])]
+    d.inbounds_function = lambda p: np.reshape((p[:, 0] ** 2 + p[:, 1] ** 2 < 100), (p.shape[0], -1))
+    d.n_outside = 2; d.n_inside = 1.5; d.surface_type = 'normal'; d.absorption = 0
+    e = cls(); e.description = 'bottom cap'; e.shape = 'plane'
+    e.param_list = [np.array([0, 0, 0]), np.array([0, 0, 1])]
+    e.inbounds_function = lambda p: np.reshape((p[:, 0] ** 2 + p[:, 1] ** 2 < 100), (p.shape[0], -1))
+    e.n_outside = 1.5; e.n_inside = 1.5; e.surface_type = 'normal'; e.absorption = 1
+    return [a, b, c, d, e]
+
+
+def unifiedtest(cls=Surf, params=(0, 0, .25, .5, .1), n_panel_in=np.inf, n_med=1.5):
+    """python/UnifiedTest.py:12-37: absorbing hemisphere over a UNIFIED panel."""
+    h = cls(); h.description = 'hemisphere'; h.shape = 'sphere'
+    h.param_list = [np.array([0, 0, 0]), 10]
+    h.inbounds_function = lambda p: np.reshape((p[:, 2, :] >= 0) * (p[:, 2, :] <= 10), (p.shape[0], -1))
+    h.n_outside = np.inf; h.n_inside = n_med; h.surface_type = 'normal'; h.absorption = 1
+    q = cls(); q.description = 'panel'; q.shape = 'plane'
+    q.param_list = [np.array([0, 0, 0]), np.array([0, 0, 1])]
+    q.inbounds_function = lambda p: np.reshape((p[:, 0] ** 2 + p[:, 1] ** 2) < 100, (p.shape[0], -1))
+    q.n_outside = n_med; q.n_inside = n_panel_in; q.surface_type = 'unified'
+    q.unifiedparams = list(params); q.absorption = 0
+    return [h, q]
+
+
+def unifiedtest_rays(n):
+    """python/UnifiedTest.py:43-62: n identical rays from (-5,0,5) towards the origin."""
+    sp = np.tile(np.array([-5.0, 0.0, 5.0]), (n, 1))
+    rays = np.zeros((n, 10))
+    rays[:, 3] = 1; rays[:, 6] = 1
+    rays[:, 0] = 1; rays[:, 1] = 0; rays[:, 2] = -1
+    return sp, rays
+
+
+def spheretest(cls=Surf):
+    """python/SphereTest.py:20-31: one absorbing sphere."""
+    s = cls(); s.description = 'sphere'; s.shape = 'sphere'
+    s.param_list = [np.array([0, 0, 0]), 10]
+    s.inbounds_function = lambda p: np.reshape((p[:, 2, :] >= -10) * (p[:, 2, :] <= 10), (p.shape[0], -1))
+    s.n_outside = np.inf; s.n_inside = 2; s.surface_type = 'normal'; s.absorption = 1
+    return [s]
+
+
+RI_FIELDS = ("incoming_ray", "reflected_ray", "refracted_ray", "intersection_point", "surface_normal", "ray_index",
+             "surface_index", "distance_traveled", "n_incident", "n_transmitted", "bulkabs_incident",
+             "bulkabs_transmitted", "rayleigh_incident", "rayleigh_transmitted")
+
+
+def pack_interfaces(ris, prefix="s"):
+    """list of rayInterfaces -> dict of arrays for np.savez"""
+    d = {"num_interfaces": np.array(len(ris))}
+    for k, ri in enumerate(ris):
+        for f in RI_FIELDS:
+            d["%s%d_%s" % (prefix, k, f)] = np.asarray(getattr(ri, f), dtype=np.float64)
+    return d
+
+
+def unpack_interfaces(z, prefix="s"):
+    out = []
+    for k in range(int(z["num_interfaces"])):
+        ri = types.SimpleNamespace()
+        for f in RI_FIELDS:
+            setattr(ri, f, z["%s%d_%s" % (prefix, k, f)])
+        out.append(ri)
+    return out
