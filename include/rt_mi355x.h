@@ -111,8 +111,10 @@ typedef struct rt_params {
  *  of the ray arriving there, [13..15] surface normal, [16] surface_index (reference convention) [17] orientation
  *  [18] ray_index [19] number of interactions [20] s0 still followed after it
  *  [21] status: 0 escaped geometry, 1 absorbed / below threshold, 2 max_scatters reached, 3 none (never hit)
- *  [22..23] reserved.  Non-dice mode: rows describe the never-reflected (positive ray_index) lineage. */
-#define RT_FINAL_COLS 24
+ *  [22..24] direction, [25..27] polref, [28..30] s1..s3 of the ray followed after it (refracted child if followed,
+ *  else reflected) [31] reserved.  Non-dice mode: rows describe the lineage that keeps following the refracted
+ *  child when there is one.  A ray that never interacts keeps its input values in [0..12] and status 3. */
+#define RT_FINAL_COLS 32
 
 typedef struct rt_ctx rt_ctx;
 

@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ROW, ATOM, REC, FIN = 32, 12, 48, 24
+ROW, ATOM, REC, FIN = 32, 12, 48, 32
 SHAPES = {"plane": 0, "sphere": 1, "cylinder": 2, "quadsurface": 3, "torus": 4}
 STYPES = {"normal": 0, "diffuse": 1, "unified": 2, "retro": 3}
 COMPAT = {"python": 1, "python-strict": 3, "matlab": 0}

@@ -1,0 +1,582 @@
+// rt_device.hpp -- per-ray arithmetic of the RayTracer2 propagation loop for gfx950 (FP64 VALU).
+//
+// Everything here is a __host__ __device__ inline function of one ray, so that the HIP kernels in
+// rt_kernels.hip inline it into the persistent bounce kernel, and so that tests/hostsim can compile the very
+// same text with g++ to debug parity on a machine without a GPU (test aid only: the product has no CPU path).
+//
+// Reference lines are cited per function.  Unlike the oracle (oracle/rt_oracle.c), which restates the
+// reference's formulas literally, this file is free to reorganise the algebra for the GPU:
+//   * nearest-hit search keeps only (distance, surface, orientation); point and normal are recomputed for the
+//     winner, orientation comes from the sign of b/2 + l*a instead of a normalised normal;
+//   * Fresnel is evaluated in Mueller form (no complex amplitudes, atan2 or exp);
+//   * the torus quartic is depressed geometrically (origin moved to the point of closest approach to the torus
+//     centre), solved by Ferrari's resolvent and polished by Newton in registers.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifndef RT_HD
+#define RT_HD __host__ __device__ __forceinline__
+#endif
+#ifndef RT_ANY
+#define RT_ANY(x) (x) /* host build: one ray at a time.  device build: wave-wide any() */
+#endif
+
+namespace rt {
+
+constexpr int ROW = 32, ATOM = 12, REC = 48, FIN = 32;
+constexpr double TWO_PI = 6.283185307179586476925286766559;
+enum { SH_PLANE = 0, SH_SPHERE = 1, SH_CYL = 2, SH_QUAD = 3, SH_TORUS = 4 };
+enum { ST_NORMAL = 0, ST_DIFFUSE = 1, ST_UNIFIED = 2, ST_RETRO = 3 };
+enum { COMPAT_PY_INDEX = 1, COMPAT_PY_ROOT2 = 2 };
+enum { FLAG_FULL = 1, FLAG_SINGLE = 2, FLAG_FINAL = 4 };
+enum { RF_HAS_REFL = 1, RF_PRIMARY = 2, RF_BORN_REFL = 4 };
+
+struct V3 { double x, y, z; };
+RT_HD V3 operator+(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+RT_HD V3 operator-(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+RT_HD V3 operator-(V3 a) { return { -a.x, -a.y, -a.z }; }
+RT_HD V3 operator*(double s, V3 a) { return { s * a.x, s * a.y, s * a.z }; }
+RT_HD V3 operator*(V3 a, double s) { return { s * a.x, s * a.y, s * a.z }; }
+RT_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD V3 cross(V3 a, V3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+RT_HD V3 ld3(const double* p) { return { p[0], p[1], p[2] }; }
+RT_HD V3 normalized_if(V3 a) { double n = dot(a, a); if (n > 0) { double s = 1.0 / sqrt(n); return s * a; } return a; }
+RT_HD int isgn(double x) { return (x > 0) - (x < 0); }
+
+struct Ray10 { V3 d, pol; double s0, s1, s2, s3; };
+
+// geometry tables (LDS on the device)
+struct Geom { const double* surf; const double* atoms; const uint32_t* code; int S; const double* lut; int lut_prec; };
+struct Prm {
+    int K, flags, compat, maxiter, base;
+    double min_travel, thrA, thrB, tir;
+    uint32_t key0, key1;
+};
+
+// ---------------------------------------------------------------------------------------------- RNG
+// Philox4x32-10; counter = (ray_id lo, ray_id hi, path hash, step << 20 | block); two 53-bit uniforms per block.
+// Same convention as the oracle so that Monte-Carlo runs can be compared ray by ray.
+struct Rng { uint32_t c0, c1, c2, step, k0, k1, idx; uint32_t o0, o1, o2, o3; };
+RT_HD void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+RT_HD void rng_init(Rng& g, uint32_t k0, uint32_t k1, int64_t ray_id, uint32_t hash, int step) {
+    g.c0 = (uint32_t)(uint64_t)ray_id; g.c1 = (uint32_t)((uint64_t)ray_id >> 32); g.c2 = hash; g.step = (uint32_t)step;
+    g.k0 = k0; g.k1 = k1; g.idx = 0; g.o0 = g.o1 = g.o2 = g.o3 = 0;
+}
+RT_HD double rng_uniform(Rng& g) {
+    uint32_t which = g.idx & 1u;
+    if (!which) philox(g.c0, g.c1, g.c2, (g.step << 20) | ((g.idx >> 1) & 0xFFFFFu), g.k0, g.k1, g.o0, g.o1, g.o2, g.o3);
+    uint32_t a = which ? g.o2 : g.o0, b = which ? g.o3 : g.o1;
+    g.idx++;
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+RT_HD double rng_normal(Rng& g) {
+    double u1 = rng_uniform(g), u2 = rng_uniform(g);
+    return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2);
+}
+RT_HD uint32_t path_hash(uint32_t h, int step, int reflected) {
+    h ^= (uint32_t)(2 * step + reflected + 1) * 0x9E3779B9u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------- bounds program
+// include/rt_mi355x.h "Bounds program"; replaces surface.inbounds_function (python/surface.py:19-32,
+// called at python/RayTracer2.py:316).  The program is the same for every lane: control flow is wave-uniform.
+RT_HD bool inbounds(const Geom& G, int off, int len, V3 p) {
+    if (len == 0) return true;
+    uint32_t st = 0;
+    for (int i = 0; i < len; i++) {
+        uint32_t ins = G.code[off + i], op = ins >> 24, arg = ins & 0xFFFFFFu, b;
+        if (op == 1) {
+            const double* a = G.atoms + (size_t)arg * ATOM;
+            int kind = (int)a[0], cmp = (int)a[1];
+            double rhs = a[2], v;
+            if (kind == 3) { int ax = (int)a[3]; v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z); }
+            else if (kind == 1) v = a[9] * p.x + a[10] * p.y + a[11] * p.z;
+            else if (kind == 0) v = a[3] * p.x * p.x + a[4] * p.y * p.y + a[5] * p.z * p.z + a[6] * p.x * p.y + a[7] * p.x * p.z + a[8] * p.y * p.z + a[9] * p.x + a[10] * p.y + a[11] * p.z;
+            else v = atan2(a[3] * p.x + a[4] * p.y + a[5] * p.z + a[6], a[7] * p.x + a[8] * p.y + a[9] * p.z + a[10]);
+            b = cmp == 0 ? (v < rhs) : cmp == 1 ? (v <= rhs) : cmp == 2 ? (v > rhs) : cmp == 3 ? (v >= rhs) : cmp == 4 ? (v == rhs) : (v != rhs);
+            st = (st << 1) | b;
+        } else if (op == 2) { b = (st & 1u) & ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
+        else if (op == 3) { b = (st & 1u) | ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
+        else if (op == 4) st ^= 1u;
+        else if (op == 5) st = (st << 1) | 1u;
+        else if (op == 6) st = (st << 1);
+        else if (op == 7) { b = (st & 1u) ^ ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
+    }
+    return (st & 1u) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------- nearest hit
+struct Hit { double l; int surf; int orient; };
+
+// depressed quartic y^4 + p y^2 + q y + r = 0: real roots into y[0..3], returns count.  Stands in for the
+// per-ray roots() of MATLAB/RayToX/RayToTorus.m:137-141.
+RT_HD void solve_depressed_quartic(double p, double q, double r, double& y0, double& y1, double& y2, double& y3) {
+    // all four slots are always written (NaN = no real root there): static register indices only
+    y0 = y1 = y2 = y3 = NAN;
+    double scale = fabs(p) + sqrt(fabs(r)) + 1e-300;
+    if (fabs(q) <= 1e-14 * scale * sqrt(scale)) { // biquadratic
+        double disc = p * p - 4 * r;
+        if (disc >= 0) {
+            double sq = sqrt(disc), w1 = 0.5 * (-p + sq), w2 = 0.5 * (-p - sq);
+            if (w1 >= 0) { double s = sqrt(w1); y0 = s; y1 = -s; }
+            if (w2 >= 0) { double s = sqrt(w2); y2 = s; y3 = -s; }
+        }
+    } else {
+        // largest real root z > 0 of z^3 + 2p z^2 + (p^2 - 4r) z - q^2 = 0
+        double A = -p * p / 3.0 - 4 * r, B = -2 * p * p * p / 27.0 + 8 * p * r / 3.0 - q * q;
+        double hB = 0.5 * B, tA = A / 3.0, D = hB * hB + tA * tA * tA, w;
+        if (D > 0) { double sD = sqrt(D); w = cbrt(-hB + sD) + cbrt(-hB - sD); }
+        else { double m = sqrt(-tA), c = -hB / (m * m * m); c = c > 1 ? 1 : (c < -1 ? -1 : c); w = 2 * m * cos(acos(c) / 3.0); }
+        double z = w - 2 * p / 3.0, c1 = 2 * p, c2 = p * p - 4 * r, c3 = -q * q;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            double f = ((z + c1) * z + c2) * z + c3, fp = (3 * z + 2 * c1) * z + c2;
+            if (fp != 0) { double zn = z - f / fp; if (zn > 0 && isfinite(zn)) z = zn; }
+        }
+        if (z > 0) {
+            double s = sqrt(z), qs = q / s, t = 0.5 * (p + z - qs), u = 0.5 * (p + z + qs);
+            double d1 = z - 4 * t, d2 = z - 4 * u;
+            if (d1 >= 0) { double h = -0.5 * (s + sqrt(d1)); y0 = h; y1 = (h != 0) ? t / h : 0.0; } // y^2 + s y + t
+            if (d2 >= 0) { double h = 0.5 * (s + sqrt(d2)); y2 = h; y3 = (h != 0) ? u / h : 0.0; }  // y^2 - s y + u
+        }
+    }
+#define RT_POLISH(v)                                                                                 \
+    {                                                                                                \
+        for (int it = 0; it < 2; it++) {                                                             \
+            double f = ((v * v + p) * v + q) * v + r, fp = (4 * v * v + 2 * p) * v + q;              \
+            if (fp != 0) { double vn = v - f / fp; if (isfinite(vn)) v = vn; }                       \
+        }                                                                                            \
+    }
+    RT_POLISH(y0) RT_POLISH(y1) RT_POLISH(y2) RT_POLISH(y3)
+#undef RT_POLISH
+}
+
+// One candidate root: the running strict-< minimum over (surface order, root order) reproduces
+// python/RayTracer2.py:316-321 (per-surface argmin, first index wins ties) followed by :362 (strict <).
+#define RT_CONSIDER(lv, ov)                                                                      \
+    {                                                                                            \
+        double l_ = (lv); int o_ = (ov);                                                         \
+        bool c_ = (l_ > lmin) && (l_ < h.l) && (o_ != 0);                                        \
+        if (RT_ANY(c_)) { if (c_) { V3 p_ = sp + l_ * d; if (inbounds(G, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; } } } \
+    }
+
+RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, Hit& h) {
+    h.l = INFINITY; h.surf = -1; h.orient = 0;
+    const bool py2 = (P.compat & COMPAT_PY_ROOT2) != 0;
+    for (int n = 0; n < G.S; n++) {
+        const double* row = G.surf + n * ROW;
+        const double* g = row + 2;
+        int shape = (int)row[0], boff = (int)row[27], blen = (int)row[28];
+        double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
+        if (shape == SH_PLANE) { // RayToPlane.py:35-45
+            V3 pn = ld3(g + 3);
+            double den = dot(d, pn), num = dot(ld3(g) - sp, pn);
+            RT_CONSIDER(num / den, -isgn(den));
+        } else if (shape == SH_SPHERE) { // RayToSphere.m:72-87
+            V3 x = sp - ld3(g);
+            double r = g[3], a = dot(d, d), b = 2 * dot(d, x), c = dot(x, x) - r * r, disc = b * b - 4 * a * c;
+            if (RT_ANY(disc >= 0)) {
+                double hh = 0.5 * sqrt(disc) / a, m = -0.5 * b / a; // NaN if disc < 0: fails every comparison
+                double l0 = m + hh, l1 = py2 ? -(m + hh) : m - hh;
+                RT_CONSIDER(l0, -isgn((0.5 * b + l0 * a) / r));
+                RT_CONSIDER(l1, -isgn((0.5 * b + l1 * a) / r));
+            }
+        } else if (shape == SH_CYL) { // RayToCylinder.m:84-122
+            V3 ax = ld3(g + 3), x = sp - ld3(g);
+            double r = g[6], xa = dot(x, ax), da = dot(d, ax);
+            V3 u = xa * ax - x, v = da * ax - d;
+            double a = dot(v, v), b = 2 * dot(u, v), c = dot(u, u) - r * r, l0, l1;
+            if (a != 0) {
+                double disc = b * b - 4 * a * c, hh = 0.5 * sqrt(disc) / a, m = -0.5 * b / a;
+                l0 = m + hh; l1 = py2 ? -(m + hh) : m - hh;
+            } else if (b != 0) { l0 = l1 = -c / b; }
+            else { l0 = l1 = NAN; }
+            RT_CONSIDER(l0, -isgn((0.5 * b + l0 * a) / r));
+            RT_CONSIDER(l1, -isgn((0.5 * b + l1 * a) / r));
+        } else if (shape == SH_QUAD) { // RayToQuadsurface.m:83-123
+            const double* Q = g; V3 Pv = ld3(g + 9); double R = g[12];
+            V3 dQ = { d.x * Q[0] + d.y * Q[3] + d.z * Q[6], d.x * Q[1] + d.y * Q[4] + d.z * Q[7], d.x * Q[2] + d.y * Q[5] + d.z * Q[8] };
+            V3 sQ = { sp.x * Q[0] + sp.y * Q[3] + sp.z * Q[6], sp.x * Q[1] + sp.y * Q[4] + sp.z * Q[7], sp.x * Q[2] + sp.y * Q[5] + sp.z * Q[8] };
+            double a = dot(dQ, d), sQd = dot(sQ, d), dP = dot(d, Pv), b = dP + dot(dQ, sp) + sQd, c = R + dot(sp, Pv) + dot(sQ, sp);
+            bool lin = (b != 0) && (fabs(4 * a * c / (b * b)) < 100 * 2.220446049250313e-16);
+            double l0, l1;
+            if (lin) { l0 = -c / b; l1 = -b / a; }
+            else if (a != 0) { double disc = b * b - 4 * a * c, hh = 0.5 * sqrt(disc) / a, m = -0.5 * b / a; l0 = m + hh; l1 = m - hh; }
+            else { l0 = l1 = NAN; }
+            double g0 = 2 * sQd + dP; // d . (2 pQ + P) = g0 + 2 l a
+            RT_CONSIDER(l0, -isgn(g0 + 2 * l0 * a));
+            RT_CONSIDER(l1, -isgn(g0 + 2 * l1 * a));
+        } else if (shape == SH_TORUS) { // RayToTorus.m:88-159
+            V3 ax = ld3(g + 3), x = sp - ld3(g);
+            double R1 = g[6], r2 = g[7];
+            double t0 = -dot(x, d) / dot(d, d);
+            V3 xs = x + t0 * d;
+            double X2 = dot(xs, xs), Rb = fabs(R1) + fabs(r2);
+            // the torus lies inside the sphere of radius R1+r2: nothing to solve for rays that miss it or whose
+            // nearest possible hit is beyond the best hit so far
+            bool maybe = (X2 <= Rb * Rb) && (t0 - sqrt(fmax(Rb * Rb - X2, 0.0)) < h.l);
+            if (RT_ANY(maybe)) {
+                double xa = dot(xs, ax), da = dot(d, ax), K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
+                double pp = 2 * K - R4 * (1 - da * da), qq = 2 * R4 * xa * da, rr = K * K - R4 * (X2 - xa * xa);
+                double y0, y1, y2, y3;
+                solve_depressed_quartic(pp, qq, rr, y0, y1, y2, y3);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    double ym = m == 0 ? y0 : (m == 1 ? y1 : (m == 2 ? y2 : y3));
+                    double l_ = maybe ? ym + t0 : NAN;
+                    bool c_ = (l_ > lmin) && (l_ < h.l);
+                    if (RT_ANY(c_)) {
+                        if (c_) {
+                            V3 p_ = sp + l_ * d, xx = p_ - ld3(g);
+                            double xxa = dot(xx, ax); V3 yv = xxa * ax, uu = xx - yv;
+                            double un = sqrt(dot(uu, uu));
+                            V3 nn = (1.0 / r2) * (uu * (1 - R1 / un) + yv);
+                            int o_ = -isgn(dot(d, nn));
+                            if (o_ != 0 && inbounds(G, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// geometric normal of surface row at p, already multiplied by the orientation sign (what RayToX returns as
+// surface_normals): RayToPlane.py:43, RayToSphere.py:61-63, RayToCylinder.py:120-135, RayToQuadsurface.m:116-122,
+// RayToTorus.m:149-158
+RT_HD V3 surface_normal(const double* row, V3 p, V3 d, int orient) {
+    const double* g = row + 2;
+    int shape = (int)row[0];
+    double o = (double)orient;
+    if (shape == SH_PLANE) { V3 pn = ld3(g + 3); return (-(double)isgn(dot(d, pn))) * pn; }
+    if (shape == SH_SPHERE) { return (o / g[3]) * (p - ld3(g)); }
+    if (shape == SH_CYL) { V3 ax = ld3(g + 3), y = p - ld3(g); double ya = dot(y, ax); V3 w = (1.0 / g[6]) * (ya * ax - y); return (-o) * w; }
+    if (shape == SH_QUAD) {
+        const double* Q = g;
+        V3 n = { 2 * (p.x * Q[0] + p.y * Q[3] + p.z * Q[6]) + g[9], 2 * (p.x * Q[1] + p.y * Q[4] + p.z * Q[7]) + g[10], 2 * (p.x * Q[2] + p.y * Q[5] + p.z * Q[8]) + g[11] };
+        return o * normalized_if(n);
+    }
+    V3 ax = ld3(g + 3), xx = p - ld3(g);
+    double xxa = dot(xx, ax); V3 yv = xxa * ax, uu = xx - yv;
+    double un = sqrt(dot(uu, uu));
+    return (o / g[7]) * (uu * (1 - g[6] / un) + yv);
+}
+
+// ---------------------------------------------------------------------------------------------- Fresnel
+// RefractionReflectionAtInterface.py:46-222 / .m:43-229 in Mueller form.  With hs = (s0+s1)/2, hp = (s0-s1)/2 in the
+// plane-of-incidence basis, the reference's 3x2 complex amplitude matrix collapses to
+//   s0' = hs|cs|^2 + hp|cp|^2,  s1' = hs|cs|^2 - hp|cp|^2,  s2' + i s3' = (s2 + i s3) conj(cs) cp
+// for (cs,cp) = (rs,rp) or (ts,tp), ts = sqrt(|1-|rs|^2|), tp likewise (.py:145-146).  Valid for physical Stokes
+// vectors (s0 >= |polarised part|).
+RT_HD void fresnel(const Ray10& in, V3 nrm, double n1, double n2, double tir, Ray10& refr, Ray10& refl) {
+    Ray10 r = in;
+    r.d = normalized_if(r.d);
+    V3 n = normalized_if(nrm);
+    r.pol = r.pol - dot(r.pol, r.d) * r.d;
+    r.pol = normalized_if(r.pol);
+    refr = r; refl = r; refl.d = -r.d; refl.s0 = refl.s1 = refl.s2 = refl.s3 = 0;
+    V3 md = -r.d;
+    double cos_i = dot(md, n);
+    bool goodhit = cos_i > 0;
+    V3 inorm = cross(md, n);
+    double sin_i = sqrt(dot(inorm, inorm));
+    bool goodint = sin_i > 0;
+    if (goodint) inorm = (1.0 / sin_i) * inorm;
+    double s1 = r.s1, s2 = r.s2, s3 = r.s3, s0 = r.s0;
+    if (goodint) {
+        double c_rot = dot(inorm, r.pol), s_rot = dot(cross(inorm, r.pol), r.d);
+        double c2 = c_rot * c_rot - s_rot * s_rot, sn2 = 2 * c_rot * s_rot;
+        double o1 = s1, o2 = s2;
+        s1 = o1 * c2 - o2 * sn2; s2 = o1 * sn2 + o2 * c2;
+        refr.pol = inorm; refl.pol = inorm; refr.s1 = s1; refr.s2 = s2;
+    }
+    double sin_t = sin_i * n1 / n2, arg = 1 - sin_t * sin_t, cos_t = 0;
+    double Rs, Rp, cr, ci, Ts, Tp, tst;
+    if (isinf(n2)) { Rs = 1; Rp = 1; cr = -1; ci = 0; Ts = 0; Tp = 0; tst = 0; cos_t = 1; }
+    else if (arg >= 0) {
+        cos_t = sqrt(arg);
+        double rs = (n1 * cos_i - n2 * cos_t) / (n1 * cos_i + n2 * cos_t), rp = -(n1 * cos_t - n2 * cos_i) / (n1 * cos_t + n2 * cos_i);
+        Rs = rs * rs; Rp = rp * rp; cr = rs * rp; ci = 0; Ts = fabs(1 - Rs); Tp = fabs(1 - Rp); tst = sqrt(Ts * Tp);
+    } else { // total internal reflection: |rs| = |rp| = 1, only the relative phase matters
+        double kap = sqrt(-arg), A = n1 * cos_i, B = n2 * kap, C = n1 * kap, Dd = n2 * cos_i;
+        double ia = 1.0 / (A * A + B * B), ic = 1.0 / (Dd * Dd + C * C);
+        double rsr = (A * A - B * B) * ia, rsi = -2 * A * B * ia, rpr = (Dd * Dd - C * C) * ic, rpi = -2 * C * Dd * ic;
+        Rs = 1; Rp = 1; Ts = 0; Tp = 0; tst = 0;
+        cr = rsr * rpr + rsi * rpi; ci = rsr * rpi - rsi * rpr; // conj(rs) * rp
+        if (!(arg < 0)) { Rs = Rp = cr = ci = NAN; } // NaN input
+    }
+    if (goodhit) {
+        double hs = 0.5 * (s0 + s1), hp = 0.5 * (s0 - s1);
+        refl.s0 = hs * Rs + hp * Rp; refl.s1 = hs * Rs - hp * Rp; refl.s2 = s2 * cr - s3 * ci; refl.s3 = s2 * ci + s3 * cr;
+        refr.s0 = hs * Ts + hp * Tp; refr.s1 = hs * Ts - hp * Tp; refr.s2 = s2 * tst; refr.s3 = s3 * tst;
+    }
+    V3 ny = cross(n, inorm);
+    double nyn = dot(ny, ny);
+    bool goodcut = goodhit && nyn > 0;
+    if (goodcut) {
+        ny = (1.0 / sqrt(nyn)) * ny;
+        refl.d = cos_i * n - sin_i * ny;
+        bool tircut = sin_t >= 1;
+        if (!tircut) refr.d = (-cos_t) * n - sin_t * ny;
+        else if (tir < 0) refr.d = -ny;
+        else { refr.d = refl.d; refr.pol = refl.pol; refr.s0 = refl.s0 * tir; refr.s1 = refl.s1 * tir; refr.s2 = refl.s2 * tir; refr.s3 = refl.s3 * tir; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- UNIFIED
+// UnifiedReflectorModel.m:48-320 (python :52-272 where it runs).  One Fresnel evaluation per loop pass: pass type
+// FACET draws a micro-facet and decides refraction/reflection kind; pass type SECOND applies the reflection off the
+// chosen normal (spike: mechanical normal, back: -dir, Lambertian: sampled) and ends the crossing.
+RT_HD V3 lambert_dir(Rng& g, V3 sn, V3 sx, V3 sy) { // UnifiedReflectorModel.m:309-316
+    double ct = sqrt(rng_uniform(g)), st = sqrt(1 - ct * ct), ph = TWO_PI * rng_uniform(g), sp, cp;
+    sincos(ph, &sp, &cp);
+    return ct * sn + (st * cp) * sx + (st * sp) * sy;
+}
+RT_HD V3 facet_normal(Rng& g, V3 indir, V3 sn, V3 sx, V3 sy, double sig, int maxiter) { // .m:278-306
+    V3 f = sn;
+    if (sig == 0) return f;
+    for (int it = 0; it < maxiter; it++) {
+        double th = fabs(sig * rng_normal(g)), st, ct;
+        sincos(th, &st, &ct);
+        bool out_of_range = th >= 0.5 * 3.14159265358979323846;
+        double fmx = sig * 4 < 1 ? sig * 4 : 1;
+        bool fail_jac = rng_uniform(g) * fmx > st;
+        double ph = TWO_PI * rng_uniform(g), sp, cp;
+        sincos(ph, &sp, &cp);
+        f = ct * sn + (st * cp) * sx + (st * sp) * sy;
+        bool wrong = dot(indir, f) >= 0;
+        if (!(out_of_range || fail_jac || wrong)) break;
+    }
+    return f;
+}
+RT_HD void renorm(Ray10& t, double s0) { double f = s0 / t.s0; t.s0 *= f; t.s1 *= f; t.s2 *= f; t.s3 *= f; }
+
+RT_HD Ray10 unified(Rng& g, const Ray10& in, V3 nrm, double n1, double n2, const double* prm, int maxiter) {
+    Ray10 R = in;
+    double sig = prm[0], pdiff = prm[1], c1 = prm[2], c2 = prm[2] + prm[3], c3 = prm[2] + prm[3] + prm[4];
+    R.d = normalized_if(R.d);
+    V3 N = normalized_if(nrm);
+    R.pol = R.pol - dot(R.pol, R.d) * R.d;
+    R.pol = normalized_if(R.pol);
+    V3 md = -R.d;
+    bool scattering = dot(md, N) > 0;
+    V3 sx = cross(md, N);
+    double sin_i = sqrt(dot(sx, sx));
+    if (sin_i > 0) sx = (1.0 / sin_i) * sx;
+    else {
+        V3 t = cross(V3{ 1, 0, 0 }, N);
+        if (!(dot(t, t) > 0)) t = cross(V3{ 0, 1, 0 }, N);
+        sx = (1.0 / sqrt(dot(t, t))) * t;
+    }
+    V3 sy = cross(N, sx);
+    bool insurface = false;
+    int guard = 0;
+    while (scattering && guard++ < maxiter) {
+        bool crossing = true, second = false;
+        V3 nuse = N;
+        int guard2 = 0;
+        while (crossing && guard2++ < 2 * maxiter) {
+            if (!second) nuse = facet_normal(g, R.d, N, sx, sy, sig, maxiter);
+            Ray10 refr, refl;
+            fresnel(R, nuse, n1, n2, -1.0, refr, refl);
+            if (second) { renorm(refl, R.s0); R = refl; crossing = false; second = false; continue; }
+            bool reflect_here = rng_uniform(g) > (refr.s0 / (refr.s0 + refl.s0));
+            if (!reflect_here) {
+                renorm(refr, R.s0);
+                R = refr; N = -N;
+                double t = n1; n1 = n2; n2 = t;
+                insurface = !insurface;
+                crossing = dot(R.d, N) <= 0;
+            } else {
+                double roll = rng_uniform(g);
+                if (roll < c1) { renorm(refl, R.s0); R = refl; crossing = dot(R.d, N) <= 0; }
+                else {
+                    if (roll < c2) nuse = N;
+                    else if (roll < c3) nuse = -R.d;
+                    else { V3 od = lambert_dir(g, N, sx, sy); V3 t = od - R.d; nuse = (1.0 / sqrt(dot(t, t))) * t; }
+                    second = true;
+                }
+            }
+        }
+        scattering = scattering && insurface;
+        if (scattering) { // .m:259-267: Lambertian re-emission from inside the surface material
+            R.d = lambert_dir(g, -N, sx, sy);
+            R.s1 = R.s2 = R.s3 = 0; R.s0 *= pdiff;
+            V3 t = cross(V3{ 1, 0, 0 }, R.d);
+            if (dot(t, t) <= 0) t = cross(V3{ 0, 1, 0 }, R.d);
+            R.pol = (1.0 / sqrt(dot(t, t))) * t;
+        }
+    }
+    return R;
+}
+
+// ---------------------------------------------------------------------------------------------- Rayleigh
+// MATLAB/Physics/RayleighScattering.m:62-148; lut = rayleigh_azimuth (:55-60), prec = azimuth_precision
+RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
+    Ray10 r = in;
+    r.d = normalized_if(r.d);
+    r.pol = r.pol - dot(r.pol, r.d) * r.d;
+    r.pol = normalized_if(r.pol);
+    double u1 = rng_uniform(g), u2 = rng_uniform(g), u3 = rng_uniform(g);
+    double linpol = sqrt(r.s1 * r.s1 + r.s2 * r.s2), frac = linpol / r.s0;
+    double phi = TWO_PI * u2;
+    if (frac > u1) {
+        double ang = 0.5 * atan2(r.s2, r.s1), pu = (double)prec * u2;
+        int ix = (int)floor(pu) + 1;
+        if (ix > prec) ix = prec;
+        double ixf = pu - (double)(ix - 1), a0 = lut[ix - 1], a1 = lut[ix];
+        phi = ang + a0 + ixf * (a1 - a0);
+    }
+    double c, s;
+    sincos(phi, &s, &c);
+    double c2 = c * c - s * s, sn2 = 2 * c * s, o1 = r.s1, o2 = r.s2;
+    r.s1 = o1 * c2 + o2 * sn2; r.s2 = -o1 * sn2 + o2 * c2;
+    V3 oref = r.pol, operp = cross(r.d, r.pol);
+    r.pol = c * oref + s * operp;
+    V3 nperp = cross(r.d, r.pol);
+    double a = r.s1 / r.s0, z = (2 - a) * (1 - 2 * u3), sq = sqrt(z * z + (1 - a) * (1 - a) * (1 - a) / (1 + a));
+    double A = (double)isgn(z + sq) * cbrt(fabs(z + sq)), B = (double)isgn(z - sq) * cbrt(fabs(z - sq));
+    double ct = (A + B) / cbrt(1 + a), st = sqrt(1 - ct * ct);
+    Ray10 o = r;
+    o.d = ct * r.d + (st * c) * oref + (st * s) * operp;
+    o.pol = cross(nperp, o.d);
+    double c2t = ct * ct, R11 = c2t + 1, R12 = c2t - 1, rn = r.s0 / (r.s0 * R11 + r.s1 * R12);
+    o.s1 = (r.s0 * R12 + r.s1 * R11) * rn;
+    double R33 = 2 * ct * rn;
+    o.s2 = r.s2 * R33; o.s3 = r.s3 * R33;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------- one step of one ray
+struct RayState {
+    V3 p; Ray10 r;
+    int64_t ray_id, parent;
+    uint32_t hash; int32_t k, smix_last, six_last, flags;
+};
+
+struct Bounce {
+    int scat, surf_sc, ray_sc;      // scatter_cut, surface_scatter_cut, rayleigh_scatter_cut (RayTracer2.py:404-414)
+    int smix_next, six_next, surf0, orient;
+    double l; V3 p, nmech;
+    Ray10 inc, refr, refl;
+    double n1, n2, absl1, absl2, rayl1, rayl2;
+    double bulk_abs, surf_abs, inc_intensity;
+    int fa, fb;                     // follow refracted / reflected (RayTracer2.py:518-519)
+};
+
+// python/RayTracer2.py:275-519 (MATLAB/RayTracer2.m:301-553) for one ray of the live list.
+RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
+    Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
+    q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
+    Hit h; find_hit(G, P, q.p, q.r.d, q.six_last, h);
+    b.inc_intensity = q.r.s0;
+    b.scat = 0; b.surf_sc = 0; b.ray_sc = 0; b.fa = 0; b.fb = 0; b.smix_next = 0; b.six_next = 0; b.surf0 = h.surf; b.orient = h.orient;
+    b.l = h.l;
+    if (h.surf < 0) return; // no surface ahead: rayleigh_next stays inf, so scatter_cut is false (RayTracer2.py:404)
+    const double* row = G.surf + h.surf * ROW;
+    int st = (int)row[1];
+    bool in = h.orient < 0; // RayTracer2.py:351-358
+    b.n1 = in ? row[16] : row[15]; b.n2 = in ? row[15] : row[16];
+    b.absl1 = in ? row[19] : row[18]; b.absl2 = in ? row[18] : row[19];
+    b.rayl1 = in ? row[21] : row[20]; b.rayl2 = in ? row[20] : row[21];
+    double absn = row[17];
+    V3 pn = q.p + h.l * q.r.d;
+    b.nmech = surface_normal(row, pn, q.r.d, h.orient);
+    V3 sopt = (st == ST_RETRO) ? -q.r.d : b.nmech; // RayTracer2.m:332-333
+    b.smix_next = b.six_next = (h.surf + P.base) * h.orient; // RayTracer2.py:371
+    if (st == ST_DIFFUSE) { // RayTracer2.m:394-415
+        double ct = sqrt(rng_uniform(g)), stt = sqrt(1 - ct * ct), ph = rng_uniform(g) * TWO_PI, sph, cph;
+        sincos(ph, &sph, &cph);
+        V3 xt = cross(sopt, V3{ 1, 0, 0 }), yt = cross(sopt, V3{ 0, 1, 0 });
+        if (xt.x == 0 && xt.y == 0 && xt.z == 0) xt = yt;
+        xt = (1.0 / sqrt(dot(xt, xt))) * xt;
+        yt = cross(sopt, xt);
+        V3 od = ct * sopt + (stt * cph) * xt + (stt * sph) * yt - q.r.d;
+        sopt = (1.0 / sqrt(dot(od, od))) * od;
+    }
+    b.scat = 1; // l_next < inf
+    double l_bulk = INFINITY;
+    if (b.rayl1 < INFINITY) l_bulk = -b.rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
+    b.surf_sc = h.l <= l_bulk; b.ray_sc = !b.surf_sc;
+    bool uni_sc = b.surf_sc && st == ST_UNIFIED, nor_sc = b.surf_sc && !uni_sc;
+    if (b.ray_sc) { b.six_next = 0; b.l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
+    b.p = pn;
+    double trans = exp(-b.l / b.absl1); // :424-427
+    b.bulk_abs = b.inc_intensity * (1 - trans);
+    b.inc = q.r; b.inc.s0 *= trans; b.inc.s1 *= trans; b.inc.s2 *= trans; b.inc.s3 *= trans;
+    b.refr = b.inc; b.refr.s0 = b.refr.s1 = b.refr.s2 = b.refr.s3 = 0; b.refl = b.refr;
+    if (nor_sc) fresnel(b.inc, sopt, b.n1, b.n2, P.tir, b.refr, b.refl); // :438-439
+    if (uni_sc) b.refl = unified(g, b.inc, b.nmech, b.n1, b.n2, row + 22, P.maxiter); // :443-444
+    if (b.surf_sc) { double f = 1 - absn; b.refr.s0 *= f; b.refr.s1 *= f; b.refr.s2 *= f; b.refr.s3 *= f; b.refl.s0 *= f; b.refl.s1 *= f; b.refl.s2 *= f; b.refl.s3 *= f; } // :447-449
+    if (b.ray_sc) b.refl = rayleigh(g, b.inc, G.lut, G.lut_prec); // :452-454
+    if (P.flags & FLAG_SINGLE) { // :458-467
+        double tot = b.refl.s0 + b.refr.s0;
+        bool roll = rng_uniform(g) < (b.refl.s0 / tot);
+        if (roll) b.refr = b.refl;
+        double resc = tot / b.refr.s0;
+        if (isnan(resc)) resc = 0;
+        if (isnan(tot)) tot = 0;
+        b.refr.s0 = tot; b.refr.s1 *= resc; b.refr.s2 *= resc; b.refr.s3 *= resc;
+        b.refl.s0 = b.refl.s1 = b.refl.s2 = b.refl.s3 = 0;
+    }
+    b.surf_abs = b.inc.s0 - b.refr.s0 - b.refl.s0; // :471
+    b.fa = b.refr.s0 > P.thrA; b.fb = b.refl.s0 > P.thrB; // :518-519
+}
+
+// state of a child ray (python/RayTracer2.py:531-540)
+RT_HD RayState child_of(const RayState& q, const Bounce& b, bool reflected, bool primary_goes_to_refr) {
+    RayState c;
+    c.p = b.p; c.r = reflected ? b.refl : b.refr;
+    c.ray_id = q.ray_id; c.parent = -1; c.k = q.k + 1;
+    c.hash = path_hash(q.hash, q.k, reflected ? 1 : 0);
+    c.smix_last = reflected ? b.smix_next : -b.smix_next;
+    c.six_last = b.six_next < 0 ? -b.six_next : b.six_next;
+    int f = q.flags & RF_HAS_REFL;
+    if (reflected) f |= RF_HAS_REFL | RF_BORN_REFL;
+    bool prim = (q.flags & RF_PRIMARY) && (reflected ? !primary_goes_to_refr : true);
+    if (prim) f |= RF_PRIMARY;
+    c.flags = f;
+    return c;
+}
+
+// record of one interaction, column order of include/rt_mi355x.h (RT_REC_COLS); element c goes to dst[c*stride]
+RT_HD double ray_index_of(const RayState& q, const Prm& P) { double r = (double)(q.ray_id + P.base); return (q.flags & RF_HAS_REFL) ? -r : r; }
+RT_HD void put_ray10(double* dst, size_t stride, int c, const Ray10& r) {
+    dst[(c + 0) * stride] = r.d.x; dst[(c + 1) * stride] = r.d.y; dst[(c + 2) * stride] = r.d.z;
+    dst[(c + 3) * stride] = r.pol.x; dst[(c + 4) * stride] = r.pol.y; dst[(c + 5) * stride] = r.pol.z;
+    dst[(c + 6) * stride] = r.s0; dst[(c + 7) * stride] = r.s1; dst[(c + 8) * stride] = r.s2; dst[(c + 9) * stride] = r.s3;
+}
+RT_HD void fill_record(const RayState& q, const Bounce& b, const Prm& P, double* dst, size_t stride) {
+    put_ray10(dst, stride, 0, b.inc); put_ray10(dst, stride, 10, b.refr); put_ray10(dst, stride, 20, b.refl);
+    dst[30 * stride] = b.p.x; dst[31 * stride] = b.p.y; dst[32 * stride] = b.p.z;
+    dst[33 * stride] = b.nmech.x; dst[34 * stride] = b.nmech.y; dst[35 * stride] = b.nmech.z;
+    dst[36 * stride] = ray_index_of(q, P); dst[37 * stride] = (double)b.six_next; dst[38 * stride] = b.l;
+    dst[39 * stride] = b.n1; dst[40 * stride] = b.n2; dst[41 * stride] = b.absl1; dst[42 * stride] = b.absl2;
+    dst[43 * stride] = b.rayl1; dst[44 * stride] = b.rayl2;
+    dst[45 * stride] = (double)b.orient; dst[46 * stride] = (double)b.surf0; dst[47 * stride] = (double)b.ray_sc;
+}
+// final row (RT_FINAL_COLS), rewritten at every interaction of the lineage that owns it
+RT_HD void fill_final(const RayState& q, const Bounce& b, const Prm& P, double* dst) {
+    dst[0] = b.p.x; dst[1] = b.p.y; dst[2] = b.p.z;
+    put_ray10(dst, 1, 3, b.inc);
+    dst[13] = b.nmech.x; dst[14] = b.nmech.y; dst[15] = b.nmech.z;
+    dst[16] = (double)b.six_next; dst[17] = (double)b.orient; dst[18] = ray_index_of(q, P); dst[19] = (double)(q.k + 1);
+    dst[20] = (b.fa ? b.refr.s0 : 0.0) + (b.fb ? b.refl.s0 : 0.0);
+    dst[21] = (b.fa || b.fb) ? ((q.k + 1 >= P.K) ? 2.0 : 0.0) : 1.0;
+    const Ray10& o = b.fa ? b.refr : b.refl;
+    dst[22] = o.d.x; dst[23] = o.d.y; dst[24] = o.d.z; dst[25] = o.pol.x; dst[26] = o.pol.y; dst[27] = o.pol.z;
+    dst[28] = o.s1; dst[29] = o.s2; dst[30] = o.s3; dst[31] = 0.0;
+}
+
+} // namespace rt
