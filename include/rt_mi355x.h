@@ -142,9 +142,14 @@ int rt_trace_device(rt_ctx* ctx, const double* d_soa, int64_t n, const rt_params
  * MATLAB/Examples/RunExamples/RunSBCGeometry.m:45-68) and trace them; no host arrays involved. */
 int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm);
 
-/* Launch-only variants for benchmarking: enqueue on the context's stream, do not wait. */
-int rt_trace_point_source_async(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm);
-int rt_sync(rt_ctx* ctx);
+/* The rays rt_trace_point_source would trace, copied to the host in the reference layout (for parity tests). */
+int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int64_t n, uint64_t seed, int64_t ray_id_base,
+                             double* start /*[n][3]*/, double* rays /*[n][10]*/);
+
+/* Tuning knobs (no reference counterpart): "workspace_gb" (device memory for records/queues, default 8),
+ * "refill_min" (idle lanes per wave that trigger a refill = compaction cadence, default 16),
+ * "blocks_per_cu" (0 = occupancy query), "nodice_chunk" (rays per pass in ray-splitting mode, default 2^20). */
+int rt_set_option(rt_ctx* ctx, const char* key, double value);
 
 /* Results of the last trace. */
 int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps);           /* rows of absorption_table (RayTracer2.py:542) */

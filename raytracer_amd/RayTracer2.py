@@ -1,0 +1,249 @@
+"""Drop-in for the reference's python/RayTracer2.py: same module name, same function name, same positional
+signature, same return triple -- the propagation loop itself runs in HIP kernels on an MI355X
+(raytracer_amd/csrc/rt_kernels.hip behind include/rt_mi355x.h).
+
+    [ray_interfaces, absorption_table, raytable] = RayTracer2(ray_startingpoints, rays, surfacelist, max_scat,
+            min_travel_len, follow_thresh, tir_handling, full_output, singlechild, output_raytable)
+
+Differences a caller can see, all deliberate (SURVEY.md quirk ledger):
+  * no stdout noise (Q13); scalar arguments are accepted wherever the reference insists on indexables (Q19);
+  * paths that crash or silently misbehave in the numpy port follow the MATLAB text instead: second sphere/cylinder
+    root (Q16), bulk absorption and Rayleigh scattering (Q3), diffuse/retro surfaces (Q7/Q8), torus and quadsurface
+    (Q10), UNIFIED with sigma_alpha > 0 (Q11), tir_handling >= 0 (Q6), output_raytable (Q9).  `compat='python-strict'`
+    switches Q3 and Q16 back on for bit-level comparisons with the numpy port;
+  * index conventions stay those of the numpy port by default (`compat='python'`: 0-based `n*orientation`, surface 0
+    tallied on both orientations, Q1/Q2/Q5); `compat='matlab'` gives the 1-based MATLAB ones.  Either way the
+    records carry the extra attributes `orientation`, `surface_number`, `is_rayleigh`;
+  * randomness is a counter-based Philox stream keyed by (seed, ray id, path, step): results do not depend on the
+    number of GPUs or on chunking.  `seed=None` draws the seed from numpy's global stream, so `np.random.seed()`
+    still makes runs repeatable.
+Keyword-only extras: compat, seed, device, return_final, ray_id_base, ctx.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import table as _table
+from .rayInterfaces import rayInterfaces
+
+COMPAT = {"python": _lib.COMPAT_PY_INDEX, "python-strict": _lib.COMPAT_PY_INDEX | _lib.COMPAT_PY_ROOT2, "matlab": 0}
+_CTX = {}
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context(object):
+    """One rt_ctx (one GPU, one stream) plus the geometry currently uploaded to it."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        if self.L.rt_init(int(device), C.byref(h)) != 0:
+            raise _lib.RayTracerLibraryError(self.L.rt_last_error(None).decode())
+        self.h = h
+        self.device = device
+        self._geom_key = None
+        self._lut_set = False
+        self.n_surf = 0
+
+    def close(self):
+        if self.h:
+            self.L.rt_free(self.h); self.h = None
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.L.rt_last_error(self.h).decode()
+            if msg in ("Improper input to RayTracer2", "Geometry has unrecognized shape"):
+                raise Exception(msg)
+            err = _lib.RayTracerLibraryError(msg); err.code = rc
+            raise err
+
+    def set_option(self, key, value):
+        self._check(self.L.rt_set_option(self.h, key.encode(), float(value)))
+
+    def device_info(self):
+        ncu = C.c_int32(); hbm = C.c_int64(); name = C.create_string_buffer(64)
+        self._check(self.L.rt_device_info(self.h, C.byref(ncu), C.byref(hbm), name, 64))
+        return {"n_cu": ncu.value, "hbm_bytes": hbm.value, "arch": name.value.decode()}
+
+    def set_program(self, tab, atoms, code):
+        tab = np.ascontiguousarray(tab, np.float64); atoms = np.ascontiguousarray(atoms, np.float64); code = np.ascontiguousarray(code, np.uint32)
+        self._check(self.L.rt_set_surfaces(self.h, _dp(tab), tab.shape[0], _dp(atoms), atoms.shape[0], code.ctypes.data_as(C.POINTER(C.c_uint32)), code.shape[0]))
+        self.n_surf = tab.shape[0]
+        self.table = tab
+        if np.any(np.isfinite(tab[:, 20:22])) and not self._lut_set:
+            lut = np.ascontiguousarray(_table.rayleigh_lut())
+            self._check(self.L.rt_set_rayleigh_lut(self.h, _dp(lut), lut.shape[0])); self._lut_set = True
+
+    def set_surfaces(self, surfacelist, nobulk=False):
+        key = (tuple(id(s) for s in surfacelist), nobulk, tuple(_surface_fingerprint(s) for s in surfacelist))
+        if key != self._geom_key:
+            self.set_program(*_table.compile_surfaces(surfacelist, nobulk=nobulk))
+            self._geom_key = key
+
+    def params(self, K, flags, compat, min_travel, thr, tir, seed, ray_id_base, unified_maxiter=0):
+        p = _lib.Params()
+        p.max_scatters = int(K); p.flags = int(flags); p.compat = int(compat); p.unified_maxiter = int(unified_maxiter)
+        p.min_travel_length = float(min_travel); p.follow_threshold[0] = float(thr[0]); p.follow_threshold[1] = float(thr[1])
+        p.tir_handling = float(tir); p.seed = int(seed) & 0xFFFFFFFFFFFFFFFF; p.ray_id_base = int(ray_id_base)
+        return p
+
+    # ---- results
+    def results(self, want_records, want_final, n_rays):
+        ns = C.c_int32(); self._check(self.L.rt_result_num_steps(self.h, C.byref(ns))); ns = ns.value
+        tab = np.zeros((ns, 5, self.n_surf, 2))
+        if ns:
+            self._check(self.L.rt_result_table(self.h, _dp(tab)))
+        out = {"num_steps": ns, "table": tab}
+        if want_records:
+            n = C.c_int64(); self._check(self.L.rt_result_num_records(self.h, C.byref(n))); n = n.value
+            rec = np.zeros((n, _lib.REC_COLS)); step = np.zeros(n, np.int32); ray = np.zeros(n, np.int64); par = np.zeros(n, np.int64); fl = np.zeros(n, np.int32)
+            if n:
+                self._check(self.L.rt_result_records(self.h, _dp(rec), step.ctypes.data_as(C.POINTER(C.c_int32)), ray.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     par.ctypes.data_as(C.POINTER(C.c_int64)), fl.ctypes.data_as(C.POINTER(C.c_int32))))
+            out.update(rec=rec, step=step, ray=ray, parent=par, flags=fl)
+        if want_final:
+            fin = np.zeros((n_rays, _lib.FINAL_COLS)); self._check(self.L.rt_result_final(self.h, _dp(fin))); out["final"] = fin
+        ms = C.c_double(); nl = C.c_int32(); self._check(self.L.rt_result_timing(self.h, C.byref(ms), C.byref(nl)))
+        out["kernel_ms"] = ms.value; out["n_launches"] = nl.value
+        return out
+
+    def step_counts(self, K):
+        live = np.zeros(K, np.int64); scat = np.zeros(K, np.int64)
+        self._check(self.L.rt_result_step_counts(self.h, live.ctypes.data_as(C.POINTER(C.c_int64)), scat.ctypes.data_as(C.POINTER(C.c_int64))))
+        return live, scat
+
+
+def _surface_fingerprint(s):
+    pl = getattr(s, "param_list", None)
+    try:
+        plf = tuple(float(x) for p in pl for x in np.asarray(p, float).ravel())
+    except Exception:
+        plf = None
+    up = getattr(s, "unifiedparams", None)
+    return (getattr(s, "shape", None), plf, getattr(s, "n_outside", None), getattr(s, "n_inside", None), getattr(s, "surface_type", None),
+            getattr(s, "absorption", None), None if up is None else tuple(np.asarray(up, float).ravel()),
+            tuple(None if getattr(s, n, None) is None else float(np.asarray(getattr(s, n)).ravel()[0]) if np.size(getattr(s, n)) else None for n in _table.BULK_PROPS),
+            id(getattr(s, "inbounds_function", None)))
+
+
+def get_context(device=0):
+    if device not in _CTX:
+        _CTX[device] = Context(device)
+    return _CTX[device]
+
+
+def order_records(step, ray, parent, flags, num_steps):
+    """Row order of the reference for every step: step 0 in input order; step k+1 = [refracted children in the order
+    of their parents ; reflected children in the order of their parents] (python/RayTracer2.py:531-540)."""
+    n = step.shape[0]
+    pos = np.zeros(n, np.int64)
+    out = []
+    for k in range(num_steps):
+        idx = np.nonzero(step == k)[0]
+        if idx.size == 0:
+            out.append(idx); continue
+        if k == 0:
+            o = np.argsort(ray[idx], kind="stable")
+        else:
+            born = (flags[idx] & 4) != 0
+            o = np.lexsort((ray[idx], pos[parent[idx]], born))
+        idx = idx[o]
+        pos[idx] = np.arange(idx.size)
+        out.append(idx)
+    return out
+
+
+def _interface_from(rec):
+    ri = rayInterfaces()
+    ri.incoming_ray = rec[:, 0:10].copy(); ri.refracted_ray = rec[:, 10:20].copy(); ri.reflected_ray = rec[:, 20:30].copy()
+    ri.intersection_point = rec[:, 30:33].copy(); ri.surface_normal = rec[:, 33:36].copy()
+    ri.ray_index = rec[:, 36].copy(); ri.surface_index = rec[:, 37].copy(); ri.distance_traveled = rec[:, 38].copy()
+    ri.n_incident = rec[:, 39].copy(); ri.n_transmitted = rec[:, 40].copy()
+    ri.bulkabs_incident = rec[:, 41].copy(); ri.bulkabs_transmitted = rec[:, 42].copy()
+    ri.rayleigh_incident = rec[:, 43].copy(); ri.rayleigh_transmitted = rec[:, 44].copy()
+    ri.orientation = rec[:, 45].copy(); ri.surface_number = rec[:, 46].copy(); ri.is_rayleigh = rec[:, 47].copy()
+    return ri
+
+
+def parse_args(rays, max_scat, min_travel_len, follow_thresh, tir_handling, compat):
+    """argument handling of python/RayTracer2.py:193-212, 250-255 (scalars accepted everywhere)"""
+    ft = np.atleast_1d(np.asarray(follow_thresh, dtype=np.float64)).ravel()
+    thr = (float(ft[0]), float(ft[0])) if ft.size == 1 else (float(ft[0]), float(ft[1]))
+    K = int(np.atleast_1d(max_scat).ravel()[0])
+    mtl = float(np.atleast_1d(min_travel_len).ravel()[0])
+    if tir_handling is None or np.size(tir_handling) == 0:
+        ref = thr[0] if (COMPAT[compat] & _lib.COMPAT_PY_INDEX) else thr[1]  # RayTracer2.py:252 vs RayTracer2.m:279
+        tir = 1.0 if ref > np.max(rays[:, 6]) else -1.0
+    else:
+        tir = float(np.atleast_1d(tir_handling).ravel()[0])
+    return K, mtl, thr, tir
+
+
+def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel_len=np.spacing(np.float64(1)),
+               follow_thresh=np.array([0, 0], dtype=np.float64), tir_handling=[], full_output=True, singlechild=True,
+               output_raytable=False, *, compat="python", seed=None, device=0, return_final=False, ray_id_base=0, ctx=None,
+               unified_maxiter=0):
+    # error check inputs (python/RayTracer2.py:216-217), before any device work
+    if np.size(surfacelist) == 0 or np.array(ray_startingpoints).ndim != 2 or np.array(rays).ndim != 2 or \
+            np.size(ray_startingpoints, 1) != 3 or np.size(rays, 1) != 10 or np.size(ray_startingpoints, 0) != np.size(rays, 0):
+        raise Exception('Improper input to RayTracer2')
+    if compat not in COMPAT:
+        raise ValueError("compat must be one of %r" % (sorted(COMPAT),))
+    sp = np.ascontiguousarray(ray_startingpoints, dtype=np.float64)
+    ry = np.ascontiguousarray(rays, dtype=np.float64)
+    n = ry.shape[0]
+    if n == 0:
+        raise Exception('Improper input to RayTracer2')
+    K, mtl, thr, tir = parse_args(ry, max_scat, min_travel_len, follow_thresh, tir_handling, compat)
+    # the reference normalises the caller's array in place (python/RayTracer2.py:221-222); keep that visible effect
+    if isinstance(rays, np.ndarray) and rays.dtype == np.float64:
+        with np.errstate(all="ignore"):
+            rays[:, 0:3] = rays[:, 0:3] / np.abs(np.sqrt(np.sum(rays[:, 0:3] ** 2, axis=1, keepdims=True)))
+            rays[:, 3:6] = rays[:, 3:6] / np.abs(np.sqrt(np.sum(rays[:, 3:6] ** 2, axis=1, keepdims=True)))
+    # missing optional attributes get the reference's defaults on the caller's objects (RayTracer2.py:234-248)
+    for s in surfacelist:
+        if not hasattr(s, "unifiedparams") or np.size(s.unifiedparams) == 0:
+            s.unifiedparams = [0, 1, 0, 1, 0]
+        for name in _table.BULK_PROPS:
+            if not hasattr(s, name) or np.size(getattr(s, name)) == 0:
+                setattr(s, name, np.inf)
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) * (2 ** 31) + int(np.random.randint(0, 2 ** 31 - 1))
+    c = ctx if ctx is not None else get_context(device)
+    c.set_surfaces(surfacelist, nobulk=(compat == "python-strict"))
+    want_rec = bool(full_output or output_raytable)
+    flags = (_lib.FLAG_FULL_OUTPUT if want_rec else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | (_lib.FLAG_FINAL_ROWS if return_final else 0)
+    prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
+    c._check(c.L.rt_trace(c.h, _dp(sp), _dp(ry), n, C.byref(prm)))
+    res = c.results(want_rec, return_final, n)
+    ns = res["num_steps"]
+    base = 0 if (COMPAT[compat] & _lib.COMPAT_PY_INDEX) else 1
+
+    ray_interfaces = []
+    raytable = []
+    if want_rec:
+        groups = order_records(res["step"], res["ray"], res["parent"], res["flags"], ns)
+        ris = [_interface_from(res["rec"][g]) for g in groups if g.size]
+        if output_raytable:  # MATLAB/RayTracer2.m:249-253, 543-548 (numpy port broken)
+            raytable = np.zeros((K + 1, n, 13))
+            raytable[0, :, 0:3] = sp; raytable[0, :, 3:13] = ry
+            raytable[0, :, 3:6] /= np.linalg.norm(raytable[0, :, 3:6], axis=1, keepdims=True)
+            raytable[0, :, 6:9] /= np.linalg.norm(raytable[0, :, 6:9], axis=1, keepdims=True)
+            for g in groups:
+                if not g.size:
+                    continue
+                k = int(res["step"][g[0]])
+                cut = (res["flags"][g] & 1) == 0  # never reflected <=> positive ray_index
+                ix = res["ray"][g][cut] - ray_id_base
+                raytable[k + 1, ix, 0:3] = res["rec"][g][cut, 30:33]
+                raytable[k + 1, ix, 3:13] = res["rec"][g][cut, 10:20]
+        if full_output:
+            ray_interfaces = ris
+    out = [np.array(ray_interfaces, dtype=object), res["table"], raytable]
+    if return_final:
+        out.append(res["final"])
+    return out

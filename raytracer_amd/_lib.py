@@ -1,0 +1,57 @@
+"""ctypes binding of librt_mi355x.so (include/rt_mi355x.h).  Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "librt_mi355x.so")
+_LIB = None
+
+REC_COLS, FINAL_COLS, ROW, ATOM = 48, 32, 32, 12
+FLAG_FULL_OUTPUT, FLAG_SINGLECHILD, FLAG_FINAL_ROWS = 1, 2, 4
+COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
+
+EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device",
+           "rt_trace_point_source", "rt_generate_point_source", "rt_set_option", "rt_result_num_steps", "rt_result_table",
+           "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_final", "rt_result_timing",
+           "rt_device_info")
+
+
+class Params(C.Structure):
+    _fields_ = [("max_scatters", C.c_int32), ("flags", C.c_int32), ("compat", C.c_int32), ("unified_maxiter", C.c_int32),
+                ("min_travel_length", C.c_double), ("follow_threshold", C.c_double * 2), ("tir_handling", C.c_double),
+                ("seed", C.c_uint64), ("ray_id_base", C.c_int64)]
+
+
+class RayTracerLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise RayTracerLibraryError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(hipcc --offload-arch=gfx950).  raytracer_amd has no CPU path." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    P = C.POINTER
+    L.rt_init.argtypes = [C.c_int, P(C.c_void_p)]
+    L.rt_free.argtypes = [C.c_void_p]; L.rt_free.restype = None
+    L.rt_last_error.argtypes = [C.c_void_p]; L.rt_last_error.restype = C.c_char_p
+    L.rt_set_surfaces.argtypes = [C.c_void_p, P(C.c_double), C.c_int32, P(C.c_double), C.c_int32, P(C.c_uint32), C.c_int32]
+    L.rt_set_rayleigh_lut.argtypes = [C.c_void_p, P(C.c_double), C.c_int32]
+    L.rt_trace.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double), C.c_int64, P(Params)]
+    L.rt_trace_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, P(Params)]
+    L.rt_trace_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, P(Params)]
+    L.rt_generate_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, C.c_uint64, C.c_int64, P(C.c_double), P(C.c_double)]
+    L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.rt_result_num_steps.argtypes = [C.c_void_p, P(C.c_int32)]
+    L.rt_result_table.argtypes = [C.c_void_p, P(C.c_double)]
+    L.rt_result_step_counts.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
+    L.rt_result_num_records.argtypes = [C.c_void_p, P(C.c_int64)]
+    L.rt_result_records.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int32), P(C.c_int64), P(C.c_int64), P(C.c_int32)]
+    L.rt_result_final.argtypes = [C.c_void_p, P(C.c_double)]
+    L.rt_result_timing.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int32)]
+    L.rt_device_info.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_int64), C.c_char_p, C.c_int32]
+    _LIB = L
+    return L

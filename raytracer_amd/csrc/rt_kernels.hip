@@ -1,0 +1,580 @@
+// rt_kernels.hip -- HIP kernels (gfx950) and the C ABI of include/rt_mi355x.h.
+//
+// Execution model (DESIGN.md has the long version):
+//   * k_trace is a persistent kernel.  Every lane owns one ray and keeps it in registers over all of its
+//     bounces (python/RayTracer2.py:266 `while` loop, one iteration = one call of rt::bounce).  When lanes retire
+//     (ray escaped / absorbed / below threshold / max_scatters) the wave refills them from the input queue with
+//     one wave-aggregated atomic (ballot + popcount prefix); `refill_min` is the compaction cadence.
+//   * Non-dice mode (ray splitting, RayTracer2.py:531-540): the lane keeps following one child and appends the
+//     other to an output queue (ballot + prefix sum + one atomic per wave); the host launches one generation per
+//     queue until the queue is empty.
+//   * Surface table, bounds atoms/code and the absorption_table tallies live in LDS; tallies are flushed with
+//     FP64 atomics once per workgroup.
+//   * Records (full_output) are appended structure-of-arrays with the same ballot/prefix allocation and carry
+//     (step, ray id, parent slot, born-reflected flag), from which the host rebuilds the reference's row order.
+// No scalar-cache writes, no inter-workgroup waits: every wave's exit condition (queue drained and all its lanes
+// retired, each ray bounded by max_scatters and the UNIFIED loop cap) is reached independently.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define RT_HD __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_ANY(x) (__ballot((x)) != 0ull)
+#else
+#define RT_ANY(x) (x)
+#endif
+#include "rt_device.hpp"
+#include "../../include/rt_mi355x.h"
+
+using namespace rt;
+
+static_assert(RT_REC_COLS == REC && RT_FINAL_COLS == FIN && RT_ROW == ROW && RT_ATOM == ATOM, "header/device constants differ");
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int QD = 13, QI = 2, QM = 5; // queue fields: doubles, int64 (ray_id, parent), int32 (hash,k,smix_last,six_last,flags)
+constexpr int GEN_STEP = 4095;         // Philox step reserved for ray generation
+
+struct Queue { double* d; int64_t* i; int32_t* m; int64_t cap; };
+
+struct KArgs {
+    // input
+    int mode;               // 0: initial rays, SoA in_d[f*in_stride+i]; 1: queue of spawned rays; 2: point source generated in-kernel
+    const double* in_d; const int64_t* in_i; const int32_t* in_m; int64_t in_stride; int64_t n_in;
+    int64_t ray_id_base;    // id of ray 0 of this launch's input (modes 0, 2)
+    int64_t slot_base;      // final-row index = ray_id - slot_base
+    double ox, oy, oz;      // point source
+    unsigned long long* head;
+    // spawn queue
+    Queue out; unsigned long long* tail;
+    // records
+    double* rec; int64_t rec_cap; unsigned long long* rec_count; int32_t* rec_step; int64_t* rec_ray; int64_t* rec_parent; int32_t* rec_flags;
+    // final rows
+    double* fin;
+    // tallies
+    double* table; unsigned long long* n_live; unsigned long long* n_scat;
+    int* overflow;
+    // geometry
+    const double* surf; int S; const double* atoms; int n_atoms; const uint32_t* code; int n_code; const double* lut; int lut_prec;
+    Prm P;
+    int rows_lds;           // absorption_table rows kept in LDS (the rest goes straight to global atomics)
+    int refill_min;         // refill when at least this many lanes of the wave are idle (or all are)
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// reference tally rule (python/RayTracer2.py:474-486, 521-528) into LDS rows / global rows
+__device__ __forceinline__ void tally_add(const KArgs& a, double* lds_tab, int k, int cat, int smix, double v) {
+    const int S = a.S, base = a.P.base;
+    int idx, o, both = 0;
+    if (smix == 0) { if (base != 0 || S <= 0) return; idx = 0; o = 0; both = 1; }
+    else { idx = (smix > 0 ? smix : -smix) - base; if (idx < 0 || idx >= S) return; o = smix > 0 ? 0 : 1; }
+    size_t e = ((size_t)(k * 5 + cat) * S + idx) * 2 + o;
+    if (k < a.rows_lds) { atomicAdd(&lds_tab[e], v); if (both) atomicAdd(&lds_tab[e + 1], v); }
+    else { atomicAdd(&a.table[e], v); if (both) atomicAdd(&a.table[e + 1], v); }
+}
+
+__device__ __forceinline__ void gen_point_ray(const KArgs& a, int64_t ray_id, V3& p, Ray10& r) {
+    // MATLAB/Examples/RunExamples/RunSBCGeometry.m:45-68: isotropic direction, unpolarised, s0 = 1, polref = x^ x d
+    Rng g; rng_init(g, a.P.key0, a.P.key1, ray_id, 0u, GEN_STEP);
+    double ct = 1 - 2 * rng_uniform(g), st = sqrt(1 - ct * ct), ph = TWO_PI * rng_uniform(g), sp, cp;
+    sincos(ph, &sp, &cp);
+    p = V3{ a.ox, a.oy, a.oz };
+    r.d = V3{ st * cp, st * sp, ct };
+    V3 t = cross(V3{ 1, 0, 0 }, r.d);
+    if (dot(t, t) == 0) t = cross(V3{ 0, 1, 0 }, r.d);
+    r.pol = (1.0 / sqrt(dot(t, t))) * t;
+    r.s0 = 1; r.s1 = r.s2 = r.s3 = 0;
+}
+
+__device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& q) {
+    if (a.mode == 1) {
+        const double* d = a.in_d; const int64_t st = a.in_stride;
+        q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
+        q.r.d = V3{ d[3 * st + idx], d[4 * st + idx], d[5 * st + idx] };
+        q.r.pol = V3{ d[6 * st + idx], d[7 * st + idx], d[8 * st + idx] };
+        q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
+        q.ray_id = a.in_i[idx]; q.parent = a.in_i[st + idx];
+        q.hash = (uint32_t)a.in_m[idx]; q.k = a.in_m[st + idx]; q.smix_last = a.in_m[2 * st + idx]; q.six_last = a.in_m[3 * st + idx]; q.flags = a.in_m[4 * st + idx];
+        return;
+    }
+    q.ray_id = a.ray_id_base + idx; q.parent = -1; q.hash = 0; q.k = 0; q.smix_last = 1; q.six_last = 0; q.flags = RF_PRIMARY; // RayTracer2.py:258-262
+    if (a.mode == 2) gen_point_ray(a, q.ray_id, q.p, q.r);
+    else {
+        const double* d = a.in_d; const int64_t st = a.in_stride;
+        q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
+        V3 dir = V3{ d[3 * st + idx], d[4 * st + idx], d[5 * st + idx] }, pol = V3{ d[6 * st + idx], d[7 * st + idx], d[8 * st + idx] };
+        q.r.d = (1.0 / sqrt(dot(dir, dir))) * dir; q.r.pol = (1.0 / sqrt(dot(pol, pol))) * pol; // RayTracer2.py:221-222
+        q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
+    }
+    if (a.P.flags & FLAG_FINAL) { // row of a ray that never interacts
+        double* f = a.fin + (q.ray_id - a.slot_base) * FIN;
+        f[0] = q.p.x; f[1] = q.p.y; f[2] = q.p.z;
+        put_ray10(f, 1, 3, q.r);
+#pragma unroll
+        for (int j = 13; j < FIN; j++) f[j] = 0.0;
+        f[18] = ray_index_of(q, a.P); f[21] = 3.0;
+    }
+}
+
+__device__ __forceinline__ void store_ray(const Queue& Q, int64_t idx, const RayState& c) {
+    double* d = Q.d; const int64_t st = Q.cap;
+    d[0 * st + idx] = c.p.x; d[1 * st + idx] = c.p.y; d[2 * st + idx] = c.p.z;
+    d[3 * st + idx] = c.r.d.x; d[4 * st + idx] = c.r.d.y; d[5 * st + idx] = c.r.d.z;
+    d[6 * st + idx] = c.r.pol.x; d[7 * st + idx] = c.r.pol.y; d[8 * st + idx] = c.r.pol.z;
+    d[9 * st + idx] = c.r.s0; d[10 * st + idx] = c.r.s1; d[11 * st + idx] = c.r.s2; d[12 * st + idx] = c.r.s3;
+    Q.i[idx] = c.ray_id; Q.i[st + idx] = c.parent;
+    Q.m[idx] = (int32_t)c.hash; Q.m[st + idx] = c.k; Q.m[2 * st + idx] = c.smix_last; Q.m[3 * st + idx] = c.six_last; Q.m[4 * st + idx] = c.flags;
+}
+
+// slot allocation for the lanes that are active here: one atomic per wave, consecutive slots in lane order
+__device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* counter) {
+    unsigned long long act = __ballot(1);
+    int lane = lane_id(), leader = __ffsll((long long)act) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(act));
+    unsigned int lo = __shfl((unsigned int)base, leader), hi = __shfl((unsigned int)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    return base + (unsigned long long)__popcll(act & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(BLOCK) k_trace(const KArgs a) {
+    extern __shared__ double smem[];
+    // LDS image: surface rows | atoms | tally rows | code | per-step counters
+    double* s_surf = smem;
+    double* s_atoms = s_surf + a.S * ROW;
+    double* s_tab = s_atoms + a.n_atoms * ATOM;
+    const int ntab = a.rows_lds * 5 * a.S * 2;
+    uint32_t* s_code = (uint32_t*)(s_tab + ntab);
+    uint32_t* s_live = s_code + ((a.n_code + 1) & ~1);
+    uint32_t* s_scat = s_live + a.P.K;
+    for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
+    for (int i = threadIdx.x; i < a.n_atoms * ATOM; i += BLOCK) s_atoms[i] = a.atoms[i];
+    for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
+    for (int i = threadIdx.x; i < a.n_code; i += BLOCK) s_code[i] = a.code[i];
+    for (int i = threadIdx.x; i < 2 * a.P.K; i += BLOCK) s_live[i] = 0u;
+    __syncthreads();
+
+    Geom G{ s_surf, s_atoms, s_code, a.S, a.lut, a.lut_prec };
+    const Prm P = a.P;
+    const int lane = lane_id();
+    RayState q;
+    bool alive = false, more = true;
+    const bool full = (P.flags & FLAG_FULL) != 0, wantfin = (P.flags & FLAG_FINAL) != 0;
+
+    for (;;) {
+        if (more) {
+            unsigned long long need = __ballot(!alive);
+            int cnt = __popcll(need);
+            if (cnt >= a.refill_min || __ballot(alive) == 0ull) {
+                int leader = __ffsll((long long)need) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(a.head, (unsigned long long)cnt);
+                unsigned int lo = __shfl((unsigned int)base, leader), hi = __shfl((unsigned int)(base >> 32), leader);
+                base = ((unsigned long long)hi << 32) | lo;
+                if (base >= (unsigned long long)a.n_in) more = false;
+                else {
+                    if (!alive) {
+                        unsigned long long idx = base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+                        if (idx < (unsigned long long)a.n_in) { load_ray(a, (int64_t)idx, q); alive = true; }
+                    }
+                    if (base + (unsigned long long)cnt >= (unsigned long long)a.n_in) more = false;
+                }
+            }
+        }
+        if (__ballot(alive) == 0ull) { if (!more) break; continue; }
+        if (alive) {
+            Bounce b;
+            bounce(G, P, q, b);
+            const int k = q.k;
+            atomicAdd(&s_live[k], 1u);
+            if (!b.scat) { // escaped: RayTracer2.py:485-486
+                tally_add(a, s_tab, k, 2, q.smix_last, b.inc_intensity);
+                alive = false;
+            } else {
+                atomicAdd(&s_scat[k], 1u);
+                if (b.surf_sc) tally_add(a, s_tab, k, 0, b.smix_next, b.surf_abs);
+                tally_add(a, s_tab, k, 1, b.smix_next, b.bulk_abs);
+                tally_add(a, s_tab, k, 3, b.smix_next, (b.fa ? 0.0 : b.refr.s0) + (b.fb ? 0.0 : b.refl.s0));
+                tally_add(a, s_tab, k, 4, b.smix_next, (b.fa ? b.refr.s0 : 0.0) + (b.fb ? b.refl.s0 : 0.0));
+                int64_t myslot = -1;
+                if (full) {
+                    unsigned long long slot = wave_alloc(a.rec_count);
+                    if (slot < (unsigned long long)a.rec_cap) {
+                        fill_record(q, b, P, a.rec + slot, (size_t)a.rec_cap);
+                        a.rec_step[slot] = k; a.rec_ray[slot] = q.ray_id; a.rec_parent[slot] = q.parent; a.rec_flags[slot] = q.flags;
+                        myslot = (int64_t)slot;
+                    } else *a.overflow = 1;
+                }
+                if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + (q.ray_id - a.slot_base) * FIN);
+                const bool last = (k + 1 >= P.K);
+                if (last || !(b.fa || b.fb)) alive = false;
+                else {
+                    if (b.fa && b.fb) { // split: keep the refracted child, queue the reflected one
+                        RayState c = child_of(q, b, true, true);
+                        c.parent = myslot;
+                        unsigned long long slot = wave_alloc(a.tail);
+                        if (slot < (unsigned long long)a.out.cap) store_ray(a.out, (int64_t)slot, c);
+                        else *a.overflow = 2;
+                    }
+                    RayState c = child_of(q, b, !b.fa, b.fa != 0);
+                    c.parent = myslot;
+                    q = c;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntab; i += BLOCK) { double v = s_tab[i]; if (v != 0.0) atomicAdd(&a.table[i], v); }
+    for (int i = threadIdx.x; i < a.P.K; i += BLOCK) {
+        uint32_t v = s_live[i]; if (v) atomicAdd(&a.n_live[i], (unsigned long long)v);
+        uint32_t w = s_scat[i]; if (w) atomicAdd(&a.n_scat[i], (unsigned long long)w);
+    }
+}
+
+// host layout (start[n][3], rays[n][10]) -> SoA [13][n]
+__global__ void k_aos_to_soa(const double* start, const double* rays, int64_t n, double* soa) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int f = 0; f < 3; f++) soa[f * n + i] = start[i * 3 + f];
+    for (int f = 0; f < 10; f++) soa[(3 + f) * n + i] = rays[i * 10 + f];
+}
+// SoA records [REC][cap] -> rows [n][REC]
+__global__ void k_rec_to_rows(const double* rec, int64_t cap, int64_t n, double* rows) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * REC) return;
+    int64_t i = t / REC; int f = (int)(t % REC);
+    rows[t] = rec[(int64_t)f * cap + i];
+}
+__global__ void k_gen_point(KArgs a, int64_t n, double* start, double* rays) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 p; Ray10 r; gen_point_ray(a, a.ray_id_base + i, p, r);
+    start[i * 3] = p.x; start[i * 3 + 1] = p.y; start[i * 3 + 2] = p.z;
+    put_ray10(rays + i * 10, 1, 0, r);
+}
+
+} // namespace
+
+// ================================================================================================ host side
+struct rt_ctx {
+    int device = 0; hipStream_t stream = nullptr; int n_cu = 0; size_t hbm = 0; std::string name;
+    std::string err;
+    // geometry
+    double* d_surf = nullptr; double* d_atoms = nullptr; uint32_t* d_code = nullptr; double* d_lut = nullptr;
+    int S = 0, n_atoms = 0, n_code = 0, lut_n = 0;
+    // persistent small buffers
+    unsigned long long* d_counters = nullptr; // head, tail, rec_count + overflow(int)
+    double* d_table = nullptr; size_t table_elems = 0; unsigned long long* d_steps = nullptr; int steps_K = 0;
+    // results of the last trace
+    int K = 0; int num_steps = 0; int64_t n_rays = 0;
+    std::vector<double> table; std::vector<int64_t> n_live, n_scat;
+    std::vector<double> rec; std::vector<int32_t> rec_step, rec_flags; std::vector<int64_t> rec_ray, rec_parent;
+    std::vector<double> fin;
+    double kernel_ms = 0; int n_launches = 0;
+    // options
+    size_t workspace_bytes = (size_t)8 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 16; int blocks_per_cu = 0;
+};
+
+static std::string g_init_err;
+#define CK(call)                                                                                                           \
+    do {                                                                                                                   \
+        hipError_t e_ = (call);                                                                                            \
+        if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return -1; }                \
+    } while (0)
+
+extern "C" int rt_init(int device, rt_ctx** out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_init_err = "rt_init: no HIP device available (this library has no CPU path)"; return -1; }
+    if (device < 0 || device >= n) { g_init_err = "rt_init: bad device index"; return -1; }
+    rt_ctx* ctx = new rt_ctx; ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { g_init_err = "rt_init: cannot create stream"; delete ctx; return -1; }
+    hipDeviceProp_t pr; hipGetDeviceProperties(&pr, device);
+    ctx->n_cu = pr.multiProcessorCount; ctx->hbm = pr.totalGlobalMem; ctx->name = pr.gcnArchName;
+    if (hipMalloc(&ctx->d_counters, 64) != hipSuccess) { g_init_err = "rt_init: hipMalloc failed"; delete ctx; return -1; }
+    const char* ws = getenv("RT_WORKSPACE_GB"); if (ws && atof(ws) > 0) ctx->workspace_bytes = (size_t)(atof(ws) * (double)(1ull << 30));
+    const char* rf = getenv("RT_REFILL_MIN"); if (rf && atoi(rf) > 0) ctx->refill_min = atoi(rf);
+    const char* bc = getenv("RT_BLOCKS_PER_CU"); if (bc && atoi(bc) > 0) ctx->blocks_per_cu = atoi(bc);
+    const char* nc = getenv("RT_NODICE_CHUNK"); if (nc && atoll(nc) > 0) ctx->nodice_chunk = atoll(nc);
+    *out = ctx; return 0;
+}
+
+extern "C" void rt_free(rt_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+extern "C" int rt_device_info(rt_ctx* ctx, int32_t* n_cu, int64_t* hbm_bytes, char* name, int32_t name_len) {
+    if (n_cu) *n_cu = ctx->n_cu; if (hbm_bytes) *hbm_bytes = (int64_t)ctx->hbm;
+    if (name && name_len > 0) { strncpy(name, ctx->name.c_str(), (size_t)name_len - 1); name[name_len - 1] = 0; }
+    return 0;
+}
+
+extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
+    std::string k(key);
+    if (k == "workspace_gb") ctx->workspace_bytes = (size_t)(value * (double)(1ull << 30));
+    else if (k == "refill_min") ctx->refill_min = (int)value;
+    else if (k == "blocks_per_cu") ctx->blocks_per_cu = (int)value;
+    else if (k == "nodice_chunk") ctx->nodice_chunk = (int64_t)value;
+    else { ctx->err = "rt_set_option: unknown key " + k; return -1; }
+    return 0;
+}
+
+extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf, const double* atoms, int32_t n_atoms, const uint32_t* code, int32_t n_code) {
+    if (n_surf <= 0 || n_surf > RT_MAX_SURF) { ctx->err = "rt_set_surfaces: need 1..256 surfaces"; return -1; }
+    if (n_atoms < 0 || n_code < 0) { ctx->err = "rt_set_surfaces: negative size"; return -1; }
+    // validate what the kernel will index with
+    for (int s = 0; s < n_surf; s++) {
+        const double* r = table + (size_t)s * ROW;
+        int shape = (int)r[0], off = (int)r[27], len = (int)r[28];
+        if (shape < 0 || shape > 4) { ctx->err = "Geometry has unrecognized shape"; return -1; }
+        if (off < 0 || len < 0 || off + len > n_code) { ctx->err = "rt_set_surfaces: bounds program out of range"; return -1; }
+        int depth = 0;
+        for (int i = off; i < off + len; i++) {
+            uint32_t op = code[i] >> 24, arg = code[i] & 0xFFFFFFu;
+            if (op == 1) { if ((int)arg >= n_atoms) { ctx->err = "rt_set_surfaces: atom index out of range"; return -1; } depth++; }
+            else if (op == 5 || op == 6) depth++;
+            else if (op == 2 || op == 3 || op == 7) depth--;
+            else if (op != 4) { ctx->err = "rt_set_surfaces: bad opcode"; return -1; }
+            if (depth < 1 || depth > 32) { ctx->err = "rt_set_surfaces: bounds program stack out of range"; return -1; }
+        }
+    }
+    for (int i = 0; i < n_atoms; i++) {
+        int kind = (int)atoms[(size_t)i * ATOM], cmp = (int)atoms[(size_t)i * ATOM + 1];
+        if (kind < 0 || kind > 3 || cmp < 0 || cmp > 5) { ctx->err = "rt_set_surfaces: bad atom"; return -1; }
+        if (kind == 3) { int ax = (int)atoms[(size_t)i * ATOM + 3]; if (ax < 0 || ax > 2) { ctx->err = "rt_set_surfaces: bad coordinate atom"; return -1; } }
+    }
+    CK(hipSetDevice(ctx->device));
+    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); ctx->d_surf = ctx->d_atoms = nullptr; ctx->d_code = nullptr;
+    CK(hipMalloc(&ctx->d_surf, sizeof(double) * (size_t)n_surf * ROW));
+    CK(hipMalloc(&ctx->d_atoms, sizeof(double) * (size_t)(n_atoms > 0 ? n_atoms : 1) * ATOM));
+    CK(hipMalloc(&ctx->d_code, sizeof(uint32_t) * (size_t)(n_code > 0 ? n_code : 1)));
+    CK(hipMemcpy(ctx->d_surf, table, sizeof(double) * (size_t)n_surf * ROW, hipMemcpyHostToDevice));
+    if (n_atoms) CK(hipMemcpy(ctx->d_atoms, atoms, sizeof(double) * (size_t)n_atoms * ATOM, hipMemcpyHostToDevice));
+    if (n_code) CK(hipMemcpy(ctx->d_code, code, sizeof(uint32_t) * (size_t)n_code, hipMemcpyHostToDevice));
+    ctx->S = n_surf; ctx->n_atoms = n_atoms; ctx->n_code = n_code;
+    return 0;
+}
+
+extern "C" int rt_set_rayleigh_lut(rt_ctx* ctx, const double* lut, int32_t n) {
+    if (n < 2) { ctx->err = "rt_set_rayleigh_lut: need at least 2 entries"; return -1; }
+    CK(hipSetDevice(ctx->device));
+    hipFree(ctx->d_lut); ctx->d_lut = nullptr;
+    CK(hipMalloc(&ctx->d_lut, sizeof(double) * (size_t)n));
+    CK(hipMemcpy(ctx->d_lut, lut, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    ctx->lut_n = n; return 0;
+}
+
+namespace {
+
+struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) hipFree(p); } };
+
+int alloc_queue(rt_ctx* ctx, Queue& q, DevBuf& bd, DevBuf& bi, DevBuf& bm, int64_t cap) {
+    q.cap = cap;
+    CK(hipMalloc(&bd.p, sizeof(double) * QD * (size_t)cap)); CK(hipMalloc(&bi.p, sizeof(int64_t) * QI * (size_t)cap)); CK(hipMalloc(&bm.p, sizeof(int32_t) * QM * (size_t)cap));
+    q.d = (double*)bd.p; q.i = (int64_t*)bi.p; q.m = (int32_t*)bm.p;
+    return 0;
+}
+
+// mode 0: h_start/h_rays host arrays or d_soa device SoA; mode 2: point source
+int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm) {
+    if (!ctx->d_surf) { ctx->err = "rt_trace: no surfaces set"; return -1; }
+    if (n <= 0) { ctx->err = "Improper input to RayTracer2"; return -1; }
+    const int K = prm->max_scatters;
+    if (K < 1 || K > 4094) { ctx->err = "rt_trace: max_scatters must be in 1..4094"; return -1; }
+    CK(hipSetDevice(ctx->device));
+    const int S = ctx->S;
+    const bool full = prm->flags & RT_FLAG_FULL_OUTPUT, single = prm->flags & RT_FLAG_SINGLECHILD, wantfin = prm->flags & RT_FLAG_FINAL_ROWS;
+    bool has_rayleigh = false;
+    { std::vector<double> t((size_t)S * ROW); CK(hipMemcpy(t.data(), ctx->d_surf, t.size() * 8, hipMemcpyDeviceToHost)); for (int s = 0; s < S; s++) if (t[(size_t)s * ROW + 20] < INFINITY || t[(size_t)s * ROW + 21] < INFINITY) has_rayleigh = true; }
+    if (has_rayleigh && !ctx->d_lut) { ctx->err = "rt_trace: geometry has finite Rayleigh lengths but no azimuth table was set (rt_set_rayleigh_lut)"; return -1; }
+
+    // ---- per-call device state
+    size_t telems = (size_t)K * 5 * S * 2;
+    if (ctx->table_elems < telems) { hipFree(ctx->d_table); ctx->d_table = nullptr; CK(hipMalloc(&ctx->d_table, telems * 8)); ctx->table_elems = telems; }
+    if (ctx->steps_K < K) { hipFree(ctx->d_steps); ctx->d_steps = nullptr; CK(hipMalloc(&ctx->d_steps, sizeof(unsigned long long) * 2 * (size_t)K)); ctx->steps_K = K; }
+    CK(hipMemsetAsync(ctx->d_table, 0, telems * 8, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_steps, 0, sizeof(unsigned long long) * 2 * (size_t)K, ctx->stream));
+    ctx->K = K; ctx->n_rays = n; ctx->kernel_ms = 0; ctx->n_launches = 0;
+    ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
+    ctx->fin.clear(); if (wantfin) ctx->fin.resize((size_t)n * FIN);
+
+    // ---- LDS budget
+    const int n_atoms = ctx->n_atoms, n_code = ctx->n_code;
+    size_t fixed = (size_t)S * ROW * 8 + (size_t)n_atoms * ATOM * 8 + (size_t)((n_code + 1) & ~1) * 4 + (size_t)2 * K * 4;
+    const size_t lds_max = 64 * 1024; // keep two+ workgroups per CU resident
+    if (fixed > lds_max) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
+    size_t rowb = (size_t)5 * S * 2 * 8;
+    int rows_lds = (int)std::min<size_t>((size_t)K, (lds_max - fixed) / rowb);
+    size_t lds = fixed + (size_t)rows_lds * rowb;
+    CK(hipFuncSetAttribute((const void*)k_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = ctx->blocks_per_cu;
+    if (bpc <= 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace, BLOCK, lds) != hipSuccess || nb < 1) nb = 1; bpc = nb > 8 ? 8 : nb; }
+
+    // ---- chunking
+    const size_t W = ctx->workspace_bytes;
+    const size_t rec_bytes = (size_t)REC * 8 + 4 + 8 + 8 + 4;
+    int64_t chunk = n, rec_cap = 0, q_cap = 0;
+    if (single) {
+        if (full) { chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(W / (rec_bytes * (size_t)K)))); rec_cap = chunk * K; }
+        if (mode == 0 && !d_soa) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (13 * 8 * 2))));
+        if (wantfin) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (FIN * 8))));
+        if (prm->follow_threshold[1] < 0) q_cap = chunk * K; // degenerate: reflected child followed as well
+    } else {
+        chunk = std::min<int64_t>(n, ctx->nodice_chunk);
+        q_cap = std::max<int64_t>(4 * chunk, 1 << 16);
+        if (full) rec_cap = std::max<int64_t>((int64_t)(W / rec_bytes), 1 << 16), rec_cap = std::min<int64_t>(rec_cap, (int64_t)1 << 31);
+    }
+    if (full && rec_cap < chunk) { rec_cap = chunk; }
+
+    DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
+    Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
+    if (q_cap > 0) { if (alloc_queue(ctx, q[0], b_q0d, b_q0i, b_q0m, q_cap)) return -1; if (alloc_queue(ctx, q[1], b_q1d, b_q1i, b_q1m, q_cap)) return -1; }
+    if (mode == 0 && !d_soa) { CK(hipMalloc(&b_in.p, 13 * 8 * (size_t)chunk)); CK(hipMalloc(&b_hs.p, 3 * 8 * (size_t)chunk)); CK(hipMalloc(&b_hr.p, 10 * 8 * (size_t)chunk)); }
+    if (full) {
+        CK(hipMalloc(&b_rec.p, (size_t)REC * 8 * (size_t)rec_cap)); CK(hipMalloc(&b_rstep.p, 4 * (size_t)rec_cap)); CK(hipMalloc(&b_rray.p, 8 * (size_t)rec_cap));
+        CK(hipMalloc(&b_rpar.p, 8 * (size_t)rec_cap)); CK(hipMalloc(&b_rflag.p, 4 * (size_t)rec_cap));
+    }
+    if (wantfin) CK(hipMalloc(&b_fin.p, (size_t)FIN * 8 * (size_t)chunk));
+
+    KArgs a; memset(&a, 0, sizeof a);
+    a.surf = ctx->d_surf; a.S = S; a.atoms = ctx->d_atoms; a.n_atoms = n_atoms; a.code = ctx->d_code; a.n_code = n_code;
+    a.lut = ctx->d_lut; a.lut_prec = ctx->lut_n > 0 ? ctx->lut_n - 1 : 1;
+    a.P.K = K; a.P.flags = prm->flags; a.P.compat = prm->compat; a.P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
+    a.P.base = (prm->compat & RT_COMPAT_PY_INDEX) ? 0 : 1; a.P.min_travel = prm->min_travel_length; a.P.thrA = prm->follow_threshold[0]; a.P.thrB = prm->follow_threshold[1];
+    a.P.tir = prm->tir_handling; a.P.key0 = (uint32_t)prm->seed; a.P.key1 = (uint32_t)(prm->seed >> 32);
+    a.table = ctx->d_table; a.n_live = ctx->d_steps; a.n_scat = ctx->d_steps + K;
+    a.head = ctx->d_counters; a.tail = ctx->d_counters + 1; a.rec_count = ctx->d_counters + 2; a.overflow = (int*)(ctx->d_counters + 3);
+    a.rec = (double*)b_rec.p; a.rec_cap = rec_cap; a.rec_step = (int32_t*)b_rstep.p; a.rec_ray = (int64_t*)b_rray.p; a.rec_parent = (int64_t*)b_rpar.p; a.rec_flags = (int32_t*)b_rflag.p;
+    a.fin = (double*)b_fin.p; a.rows_lds = rows_lds; a.refill_min = ctx->refill_min;
+    if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
+
+    hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+    int rc = 0;
+    for (int64_t off = 0; off < n && rc == 0; off += chunk) {
+        int64_t m = std::min<int64_t>(chunk, n - off);
+        CK(hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
+        a.mode = mode; a.n_in = m; a.ray_id_base = prm->ray_id_base + off; a.slot_base = prm->ray_id_base + off;
+        if (mode == 0) {
+            if (d_soa) { a.in_d = d_soa + off; a.in_stride = n; }
+            else {
+                CK(hipMemcpyAsync(b_hs.p, h_start + off * 3, 3 * 8 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+                CK(hipMemcpyAsync(b_hr.p, h_rays + off * 10, 10 * 8 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_hs.p, (const double*)b_hr.p, m, (double*)b_in.p);
+                a.in_d = (const double*)b_in.p; a.in_stride = m;
+            }
+        }
+        int cur = 0;
+        for (int gen = 0; gen <= K; gen++) {
+            a.out = q[cur];
+            int64_t blocks = std::min<int64_t>((a.n_in + BLOCK - 1) / BLOCK, (int64_t)ctx->n_cu * bpc);
+            CK(hipEventRecord(ev0, ctx->stream));
+            hipLaunchKernelGGL(k_trace, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, a);
+            CK(hipEventRecord(ev1, ctx->stream));
+            CK(hipGetLastError());
+            unsigned long long cnt[4];
+            CK(hipMemcpyAsync(cnt, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            float ms = 0; CK(hipEventElapsedTime(&ms, ev0, ev1)); ctx->kernel_ms += ms; ctx->n_launches++;
+            int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
+            if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace or lower nodice_chunk)" : "rt_trace: ray queue overflow (lower nodice_chunk)"; rc = -3; break; }
+            unsigned long long spawned = cnt[1];
+            if (spawned == 0) break;
+            // next generation reads what this one appended
+            a.mode = 1; a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap; a.n_in = (int64_t)spawned;
+            cur ^= 1;
+            CK(hipMemsetAsync(ctx->d_counters, 0, 16, ctx->stream)); // head, tail (records keep counting)
+        }
+        if (rc) break;
+        if (full) {
+            unsigned long long nrec = 0;
+            CK(hipMemcpy(&nrec, ctx->d_counters + 2, 8, hipMemcpyDeviceToHost));
+            if (nrec) {
+                size_t base = ctx->rec_step.size();
+                DevBuf rows; CK(hipMalloc(&rows.p, (size_t)REC * 8 * nrec));
+                hipLaunchKernelGGL(k_rec_to_rows, dim3((unsigned)((nrec * REC + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_rec.p, rec_cap, (int64_t)nrec, (double*)rows.p);
+                ctx->rec.resize((base + nrec) * REC); ctx->rec_step.resize(base + nrec); ctx->rec_flags.resize(base + nrec); ctx->rec_ray.resize(base + nrec); ctx->rec_parent.resize(base + nrec);
+                CK(hipMemcpyAsync(ctx->rec.data() + base * REC, rows.p, (size_t)REC * 8 * nrec, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipMemcpyAsync(ctx->rec_step.data() + base, b_rstep.p, 4 * nrec, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipMemcpyAsync(ctx->rec_flags.data() + base, b_rflag.p, 4 * nrec, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipMemcpyAsync(ctx->rec_ray.data() + base, b_rray.p, 8 * nrec, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipMemcpyAsync(ctx->rec_parent.data() + base, b_rpar.p, 8 * nrec, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipStreamSynchronize(ctx->stream));
+                for (size_t i = base; i < base + nrec; i++) if (ctx->rec_parent[i] >= 0) ctx->rec_parent[i] += (int64_t)base;
+            }
+        }
+        if (wantfin) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));
+    }
+    hipEventDestroy(ev0); hipEventDestroy(ev1);
+    if (rc) return rc;
+    // ---- tallies and the reference's step bookkeeping (RayTracer2.py:266-270, 405-407, 542)
+    ctx->table.assign(telems, 0.0); std::vector<unsigned long long> st(2 * (size_t)K);
+    CK(hipMemcpy(ctx->table.data(), ctx->d_table, telems * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st.data(), ctx->d_steps, sizeof(unsigned long long) * 2 * (size_t)K, hipMemcpyDeviceToHost));
+    ctx->n_live.assign(K, 0); ctx->n_scat.assign(K, 0);
+    int ns = 0;
+    for (int k = 0; k < K; k++) { ctx->n_live[k] = (int64_t)st[k]; ctx->n_scat[k] = (int64_t)st[K + k]; if (st[k] > 0) ns = k + 1; }
+    for (int k = 0; k < ns; k++)
+        if (ctx->n_scat[k] == 0) std::fill(ctx->table.begin() + (size_t)k * 5 * S * 2, ctx->table.begin() + (size_t)(k + 1) * 5 * S * 2, 0.0); // `continue` before the tallies
+    ctx->num_steps = ns;
+    return 0;
+}
+
+} // namespace
+
+extern "C" int rt_trace(rt_ctx* ctx, const double* start, const double* rays, int64_t n, const rt_params* prm) {
+    if (!start || !rays) { ctx->err = "Improper input to RayTracer2"; return -1; }
+    return run_trace(ctx, 0, start, rays, nullptr, nullptr, n, prm);
+}
+extern "C" int rt_trace_device(rt_ctx* ctx, const double* d_soa, int64_t n, const rt_params* prm) {
+    if (!d_soa) { ctx->err = "Improper input to RayTracer2"; return -1; }
+    return run_trace(ctx, 0, nullptr, nullptr, d_soa, nullptr, n, prm);
+}
+extern "C" int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm) {
+    return run_trace(ctx, 2, nullptr, nullptr, nullptr, origin, n, prm);
+}
+extern "C" int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int64_t n, uint64_t seed, int64_t ray_id_base, double* start, double* rays) {
+    CK(hipSetDevice(ctx->device));
+    DevBuf s, r; CK(hipMalloc(&s.p, 24 * (size_t)n)); CK(hipMalloc(&r.p, 80 * (size_t)n));
+    KArgs a; memset(&a, 0, sizeof a);
+    a.P.key0 = (uint32_t)seed; a.P.key1 = (uint32_t)(seed >> 32); a.ray_id_base = ray_id_base; a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
+    hipLaunchKernelGGL(k_gen_point, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, n, (double*)s.p, (double*)r.p);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(start, s.p, 24 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(rays, r.p, 80 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps) { *num_steps = ctx->num_steps; return 0; }
+extern "C" int rt_result_table(rt_ctx* ctx, double* table) { memcpy(table, ctx->table.data(), sizeof(double) * (size_t)ctx->num_steps * 5 * ctx->S * 2); return 0; }
+extern "C" int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live, int64_t* n_scat) {
+    memcpy(n_live, ctx->n_live.data(), 8 * (size_t)ctx->K); memcpy(n_scat, ctx->n_scat.data(), 8 * (size_t)ctx->K); return 0;
+}
+extern "C" int rt_result_num_records(rt_ctx* ctx, int64_t* n) { *n = (int64_t)ctx->rec_step.size(); return 0; }
+extern "C" int rt_result_records(rt_ctx* ctx, double* rec, int32_t* step, int64_t* ray_id, int64_t* parent, int32_t* flags) {
+    size_t n = ctx->rec_step.size();
+    if (rec) memcpy(rec, ctx->rec.data(), n * REC * 8);
+    if (step) memcpy(step, ctx->rec_step.data(), n * 4);
+    if (ray_id) memcpy(ray_id, ctx->rec_ray.data(), n * 8);
+    if (parent) memcpy(parent, ctx->rec_parent.data(), n * 8);
+    if (flags) memcpy(flags, ctx->rec_flags.data(), n * 4);
+    return 0;
+}
+extern "C" int rt_result_final(rt_ctx* ctx, double* rows) {
+    if (ctx->fin.empty()) { ctx->err = "rt_result_final: trace was run without RT_FLAG_FINAL_ROWS"; return -1; }
+    memcpy(rows, ctx->fin.data(), ctx->fin.size() * 8); return 0;
+}
+extern "C" int rt_result_timing(rt_ctx* ctx, double* kernel_ms, int32_t* n_launches) { if (kernel_ms) *kernel_ms = ctx->kernel_ms; if (n_launches) *n_launches = ctx->n_launches; return 0; }
