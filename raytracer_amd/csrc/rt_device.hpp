@@ -39,7 +39,14 @@ RT_HD V3 operator-(V3 a) { return { -a.x, -a.y, -a.z }; }
 RT_HD V3 operator*(double s, V3 a) { return { s * a.x, s * a.y, s * a.z }; }
 RT_HD V3 operator*(V3 a, double s) { return { s * a.x, s * a.y, s * a.z }; }
 RT_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-RT_HD V3 cross(V3 a, V3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+RT_HD V3 cross(V3 a, V3 b) {
+    // no FMA contraction here: a x a must be exactly zero (the reference tests `sin_incident_angle > 0`,
+    // RefractionReflectionAtInterface.py:99-100, and back-reflection uses normal = -direction)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
 RT_HD V3 ld3(const double* p) { return { p[0], p[1], p[2] }; }
 RT_HD V3 normalized_if(V3 a) { double n = dot(a, a); if (n > 0) { double s = 1.0 / sqrt(n); return s * a; } return a; }
 RT_HD int isgn(double x) { return (x > 0) - (x < 0); }
