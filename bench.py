@@ -1,0 +1,163 @@
+"""bench.py -- headline benchmark: ray-surface interactions/s on the SBC/ArBC jar geometry, full Monte-Carlo mode.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one batch: `--rays` isotropic unit-intensity rays from a point source inside
+the target fluid of the 39-surface jar geometry (MATLAB/Examples/CreateExamples/CreateArBCGeometry.m, with the bulk
+Rayleigh/absorption lengths of CreateSBCGeometry.m:40-41 and a UNIFIED reflector: SURVEY.md 8d config 5), traced with
+the arguments of MATLAB/Examples/RunExamples/RunSBCGeometry.m:73-77 (max_scatters 100, min_travel 1e-6, threshold
+1e-4, tir -1, full_output off, single child).  Rays are generated on the device, so inputs are HBM-resident by
+construction.  Rays are independent: every rank traces its own batch (weak scaling), no data-path collective; the only
+collective is the reduction of the timing/interaction counters (and, in a real run, of the absorption table).
+metric value = interactions (rows the reference would append to ray_interfaces) per second over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic flops per ray-surface test / per interaction, SURVEY.md section 8a/8d convention
+# (add/mul 1, fma 2, div/sqrt/transcendental 1)
+FLOP_SHAPE = {0: 23 + 10, 1: 85 + 20, 2: 130 + 20, 3: 175 + 20, 4: 560 + 40}
+FLOP_PHYSICS = 300 + 40          # Fresnel + bookkeeping per interaction
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (vendor figure: 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
+
+
+def flop_per_interaction(table):
+    return float(sum(FLOP_SHAPE[int(s)] for s in table[:, 0]) + FLOP_PHYSICS)
+
+
+def build_workload(name):
+    from raytracer_amd import geometries as G
+    from raytracer_amd import table as T
+    if name == "sbc_full_mc":
+        sl = G.create_arbc_geometry(G.sbc_full_mc_specs())
+        origin = (0.0, 0.0, 10.0)
+        kw = dict(K=100, min_travel=1e-6, thr=(1e-4, 1e-4), tir=-1.0)
+    elif name == "sbc_lightcollection":
+        sl = G.create_sbc_geometry()
+        origin = (0.0, 0.6, 1.3)
+        kw = dict(K=100, min_travel=1e-6, thr=(1e-4, 1e-4), tir=-1.0)
+    else:
+        raise SystemExit("unknown workload " + name)
+    prog = T.compile_surfaces(sl)
+    return sl, prog, origin, kw
+
+
+def cpu_baseline(prog, origin, kw, seed, target_seconds=12.0):
+    """CPU restatement (oracle/rt_oracle.c, compiled bounds program, OpenMP) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from raytracer_amd.RayTracer2 import Context
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    n = 20000
+    done = 0; t_used = 0.0; inter = 0
+    rng = np.random.default_rng(seed)
+    while t_used < target_seconds and done < 40:
+        ct = 1 - 2 * rng.random(n); st = np.sqrt(1 - ct * ct); ph = 2 * np.pi * rng.random(n)
+        rays = np.zeros((n, 10)); rays[:, 0] = st * np.cos(ph); rays[:, 1] = st * np.sin(ph); rays[:, 2] = ct
+        pol = np.cross(np.array([1.0, 0, 0]), rays[:, 0:3]); pol /= np.linalg.norm(pol, axis=1, keepdims=True)
+        rays[:, 3:6] = pol; rays[:, 6] = 1
+        sp = np.tile(np.asarray(origin, float), (n, 1))
+        t0 = time.perf_counter()
+        r = O.trace(sp, rays, [None] * prog[0].shape[0], kw["K"], kw["min_travel"], kw["thr"], kw["tir"], False, True, False,
+                    compat="matlab", seed=seed + done, program=prog)
+        t_used += time.perf_counter() - t0
+        inter += int(r.n_scat.sum()); done += 1
+    return {"value": inter / t_used, "unit": "interactions/s", "cores": threads, "kind": "port",
+            "sample": "%d rays (%d interactions) of the same workload through oracle/rt_oracle.c, %.1f s" % (done * n, inter, t_used)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=1 << 23, help="rays per step per GPU")
+    ap.add_argument("--workload", default="sbc_full_mc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=2024)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: raytracer_amd has no CPU path")
+    torch.cuda.set_device(local)
+
+    import ctypes as C
+    from raytracer_amd import _lib
+    from raytracer_amd.RayTracer2 import Context
+    sl, prog, origin, kw = build_workload(a.workload)
+    ctx = Context(local)
+    ctx.set_program(*prog)
+    S = prog[0].shape[0]
+    org = (C.c_double * 3)(*origin)
+    flags = _lib.FLAG_SINGLECHILD
+
+    def step(i):
+        prm = ctx.params(kw["K"], flags, 0, kw["min_travel"], kw["thr"], kw["tir"], a.seed, (rank * (a.steps + a.warmup) + i) * a.rays)
+        ctx._check(ctx.L.rt_trace_point_source(ctx.h, org, a.rays, C.byref(prm)))
+        live, scat = ctx.step_counts(kw["K"])
+        ms = C.c_double(); nl = C.c_int32(); ctx.L.rt_result_timing(ctx.h, C.byref(ms), C.byref(nl))
+        return int(scat.sum()), ms.value
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    inter = 0; kms = 0.0
+    for i in range(a.steps):
+        n, ms = step(a.warmup + i)
+        inter += n; kms += ms
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, float(inter), kms], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0]); inter_all = float(tsum[1]); kms_max = float(tmax[2])
+    else:
+        inter_all = float(inter); kms_max = kms
+    if rank == 0:
+        fpi = flop_per_interaction(prog[0])
+        kernel_s = kms / 1e3
+        ach = (inter * fpi / kernel_s) / 1e12 if kernel_s > 0 else 0.0
+        out = {
+            "metric": "ray-surface interactions/sec (node) on SBC geometry", "value": inter_all / dt, "unit": "interactions/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d-surface jar geometry, point source, MC single-child, K=%d, thr=%g, %d rays/step/GPU, full_output off"
+                                   % (a.workload, S, kw["K"], kw["thr"][0], a.rays),
+                       "rays_per_step_per_gpu": a.rays, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
+                       "ray_surface_tests_per_s": inter_all * S / dt},
+            "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                         "traffic": None, "flop_per_interaction": fpi, "kernel": "k_trace", "kernel_ms_per_step": kms / a.steps,
+                         "note": "FP64 vector path (no dense contraction, MFMA unused); hbm bytes/interaction is ~0 in the persistent kernel"},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(prog, origin, kw, a.seed)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
