@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librt_mi355x.so")
+SO_PATH = os.environ.get("RT_LIB", os.path.join(_HERE, "librt_mi355x.so"))  # RT_LIB: A/B builds of the same ABI
 _LIB = None
 
 REC_COLS, FINAL_COLS, ROW, ATOM = 48, 32, 32, 12

@@ -47,14 +47,24 @@ RT_HD V3 cross(V3 a, V3 b) {
 #endif
     return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
 }
-RT_HD V3 ld3(const double* p) { return { p[0], p[1], p[2] }; }
+template <class Ptr> RT_HD V3 ld3(Ptr p) { return { p[0], p[1], p[2] }; }
 RT_HD V3 normalized_if(V3 a) { double n = dot(a, a); if (n > 0) { double s = 1.0 / sqrt(n); return s * a; } return a; }
 RT_HD int isgn(double x) { return (x > 0) - (x < 0); }
 
 struct Ray10 { V3 d, pol; double s0, s1, s2, s3; };
 
-// geometry tables (LDS on the device)
-struct Geom { const double* surf; const double* atoms; const uint32_t* code; int S; const double* lut; int lut_prec; };
+// Wave-uniform data (surface rows walked by the surface loop, bounds atoms and code) is read through the constant
+// address space: with a uniform index hipcc then emits scalar loads (s_load into SGPRs, scalar cache) instead of
+// vector loads, so the per-surface parameters cost no VGPRs and no LDS bandwidth.  Per-lane (divergent) reads of the
+// winning surface's row go to the LDS copy `surf`.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_UNIFORM __attribute__((address_space(4)))
+#else
+#define RT_UNIFORM
+#endif
+typedef const RT_UNIFORM double* udptr;
+typedef const RT_UNIFORM uint32_t* uuptr;
+struct Geom { udptr usurf; udptr uatoms; uuptr ucode; const double* surf; int S; const double* lut; int lut_prec; };
 struct Prm {
     int K, flags, compat, maxiter, base;
     double min_travel, thrA, thrB, tir;
@@ -98,19 +108,24 @@ RT_HD uint32_t path_hash(uint32_t h, int step, int reflected) {
 // ---------------------------------------------------------------------------------------------- bounds program
 // include/rt_mi355x.h "Bounds program"; replaces surface.inbounds_function (python/surface.py:19-32,
 // called at python/RayTracer2.py:316).  The program is the same for every lane: control flow is wave-uniform.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__ double atan2_atom(double y, double x) { return atan2(y, x); } // rare: keep its registers out of the hot loop
+#else
+static inline double atan2_atom(double y, double x) { return atan2(y, x); }
+#endif
 RT_HD bool inbounds(const Geom& G, int off, int len, V3 p) {
     if (len == 0) return true;
     uint32_t st = 0;
     for (int i = 0; i < len; i++) {
-        uint32_t ins = G.code[off + i], op = ins >> 24, arg = ins & 0xFFFFFFu, b;
+        uint32_t ins = G.ucode[off + i], op = ins >> 24, arg = ins & 0xFFFFFFu, b;
         if (op == 1) {
-            const double* a = G.atoms + (size_t)arg * ATOM;
+            udptr a = G.uatoms + (size_t)arg * ATOM;
             int kind = (int)a[0], cmp = (int)a[1];
             double rhs = a[2], v;
             if (kind == 3) { int ax = (int)a[3]; v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z); }
             else if (kind == 1) v = a[9] * p.x + a[10] * p.y + a[11] * p.z;
             else if (kind == 0) v = a[3] * p.x * p.x + a[4] * p.y * p.y + a[5] * p.z * p.z + a[6] * p.x * p.y + a[7] * p.x * p.z + a[8] * p.y * p.z + a[9] * p.x + a[10] * p.y + a[11] * p.z;
-            else v = atan2(a[3] * p.x + a[4] * p.y + a[5] * p.z + a[6], a[7] * p.x + a[8] * p.y + a[9] * p.z + a[10]);
+            else v = atan2_atom(a[3] * p.x + a[4] * p.y + a[5] * p.z + a[6], a[7] * p.x + a[8] * p.y + a[9] * p.z + a[10]);
             b = cmp == 0 ? (v < rhs) : cmp == 1 ? (v <= rhs) : cmp == 2 ? (v > rhs) : cmp == 3 ? (v >= rhs) : cmp == 4 ? (v == rhs) : (v != rhs);
             st = (st << 1) | b;
         } else if (op == 2) { b = (st & 1u) & ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
@@ -128,7 +143,14 @@ struct Hit { double l; int surf; int orient; };
 
 // depressed quartic y^4 + p y^2 + q y + r = 0: real roots into y[0..3], returns count.  Stands in for the
 // per-ray roots() of MATLAB/RayToX/RayToTorus.m:137-141.
-RT_HD void solve_depressed_quartic(double p, double q, double r, double& y0, double& y1, double& y2, double& y3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_COLD __device__ __noinline__ /* out of line: its cbrt/acos temporaries stay out of the surface loop's registers */
+#else
+#define RT_COLD static inline
+#endif
+struct Roots4 { double y0, y1, y2, y3; };
+RT_COLD Roots4 solve_depressed_quartic(double p, double q, double r) {
+    double y0, y1, y2, y3;
     // all four slots are always written (NaN = no real root there): static register indices only
     y0 = y1 = y2 = y3 = NAN;
     double scale = fabs(p) + sqrt(fabs(r)) + 1e-300;
@@ -167,92 +189,94 @@ RT_HD void solve_depressed_quartic(double p, double q, double r, double& y0, dou
     }
     RT_POLISH(y0) RT_POLISH(y1) RT_POLISH(y2) RT_POLISH(y3)
 #undef RT_POLISH
+    return Roots4{ y0, y1, y2, y3 };
 }
 
-// One candidate root: the running strict-< minimum over (surface order, root order) reproduces
-// python/RayTracer2.py:316-321 (per-surface argmin, first index wins ties) followed by :362 (strict <).
-#define RT_CONSIDER(lv, ov)                                                                      \
-    {                                                                                            \
-        double l_ = (lv); int o_ = (ov);                                                         \
-        bool c_ = (l_ > lmin) && (l_ < h.l) && (o_ != 0);                                        \
-        if (RT_ANY(c_)) { if (c_) { V3 p_ = sp + l_ * d; if (inbounds(G, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; } } } \
-    }
+// torus normal (unnormalised sign only matters for the orientation): RayToTorus.m:149-158
+template <class Ptr> RT_HD V3 torus_normal(Ptr g, V3 p) {
+    V3 ax = ld3(g + 3), xx = p - ld3(g);
+    double xxa = dot(xx, ax); V3 yv = xxa * ax, uu = xx - yv;
+    double un = sqrt(dot(uu, uu));
+    return (1.0 / g[7]) * (uu * (1 - g[6] / un) + yv);
+}
 
+// Nearest valid hit over all surfaces.  Every shape first produces its candidate roots (NaN = none) and the sign of
+// d.normal there; one common loop then applies the validity tests of python/RayTracer2.py:316 and keeps a running
+// strict-< minimum over (surface order, root order), which reproduces :319-321 (per-surface argmin, first index
+// wins ties) followed by :362 (strict <).  `d` is a unit vector (normalised once per step, RayToShape.py:11-14), so
+// the leading coefficient of the sphere quadratic and of the torus quartic is taken as 1.
 RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, Hit& h) {
     h.l = INFINITY; h.surf = -1; h.orient = 0;
     const bool py2 = (P.compat & COMPAT_PY_ROOT2) != 0;
     for (int n = 0; n < G.S; n++) {
-        const double* row = G.surf + n * ROW;
-        const double* g = row + 2;
-        int shape = (int)row[0], boff = (int)row[27], blen = (int)row[28];
-        double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
+        udptr row = G.usurf + n * ROW;
+        udptr g = row + 2;
+        const int shape = (int)row[0], boff = (int)row[27], blen = (int)row[28];
+        const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
+        double l0 = NAN, l1 = NAN, l2 = NAN, l3 = NAN, s0 = 0, s1 = 0; // s = d . (outward normal) up to a positive factor
+        int M = 2;
         if (shape == SH_PLANE) { // RayToPlane.py:35-45
             V3 pn = ld3(g + 3);
             double den = dot(d, pn), num = dot(ld3(g) - sp, pn);
-            RT_CONSIDER(num / den, -isgn(den));
-        } else if (shape == SH_SPHERE) { // RayToSphere.m:72-87
+            l0 = num / den; s0 = den; M = 1;
+        } else if (shape == SH_SPHERE) { // RayToSphere.m:72-87 with a = 1: l = -B +- sqrt(B^2 - C)
             V3 x = sp - ld3(g);
-            double r = g[3], a = dot(d, d), b = 2 * dot(d, x), c = dot(x, x) - r * r, disc = b * b - 4 * a * c;
-            if (RT_ANY(disc >= 0)) {
-                double hh = 0.5 * sqrt(disc) / a, m = -0.5 * b / a; // NaN if disc < 0: fails every comparison
-                double l0 = m + hh, l1 = py2 ? -(m + hh) : m - hh;
-                RT_CONSIDER(l0, -isgn((0.5 * b + l0 * a) / r));
-                RT_CONSIDER(l1, -isgn((0.5 * b + l1 * a) / r));
+            double r = g[3], B = dot(d, x), C = dot(x, x) - r * r, D = B * B - C;
+            if (RT_ANY(D >= 0)) {
+                double sq = sqrt(D); // NaN if D < 0: fails every comparison below
+                l0 = sq - B; l1 = py2 ? -l0 : -B - sq;
+                s0 = (B + l0) * r; s1 = (B + l1) * r;
             }
         } else if (shape == SH_CYL) { // RayToCylinder.m:84-122
             V3 ax = ld3(g + 3), x = sp - ld3(g);
             double r = g[6], xa = dot(x, ax), da = dot(d, ax);
             V3 u = xa * ax - x, v = da * ax - d;
-            double a = dot(v, v), b = 2 * dot(u, v), c = dot(u, u) - r * r, l0, l1;
+            double a = dot(v, v), hb = dot(u, v), c = dot(u, u) - r * r; // hb = b/2
             if (a != 0) {
-                double disc = b * b - 4 * a * c, hh = 0.5 * sqrt(disc) / a, m = -0.5 * b / a;
-                l0 = m + hh; l1 = py2 ? -(m + hh) : m - hh;
-            } else if (b != 0) { l0 = l1 = -c / b; }
-            else { l0 = l1 = NAN; }
-            RT_CONSIDER(l0, -isgn((0.5 * b + l0 * a) / r));
-            RT_CONSIDER(l1, -isgn((0.5 * b + l1 * a) / r));
+                double ia = 1.0 / a, sq = sqrt(hb * hb - a * c);
+                l0 = (sq - hb) * ia; l1 = py2 ? -l0 : (-hb - sq) * ia;
+            } else if (hb != 0) { l0 = l1 = -0.5 * c / hb; }
+            s0 = (hb + l0 * a) * r; s1 = (hb + l1 * a) * r;
         } else if (shape == SH_QUAD) { // RayToQuadsurface.m:83-123
-            const double* Q = g; V3 Pv = ld3(g + 9); double R = g[12];
+            udptr Q = g; V3 Pv = ld3(g + 9); double R = g[12];
             V3 dQ = { d.x * Q[0] + d.y * Q[3] + d.z * Q[6], d.x * Q[1] + d.y * Q[4] + d.z * Q[7], d.x * Q[2] + d.y * Q[5] + d.z * Q[8] };
             V3 sQ = { sp.x * Q[0] + sp.y * Q[3] + sp.z * Q[6], sp.x * Q[1] + sp.y * Q[4] + sp.z * Q[7], sp.x * Q[2] + sp.y * Q[5] + sp.z * Q[8] };
             double a = dot(dQ, d), sQd = dot(sQ, d), dP = dot(d, Pv), b = dP + dot(dQ, sp) + sQd, c = R + dot(sp, Pv) + dot(sQ, sp);
-            bool lin = (b != 0) && (fabs(4 * a * c / (b * b)) < 100 * 2.220446049250313e-16);
-            double l0, l1;
+            bool lin = (b != 0) && (fabs(4 * a * c) < (100 * 2.220446049250313e-16) * (b * b));
             if (lin) { l0 = -c / b; l1 = -b / a; }
-            else if (a != 0) { double disc = b * b - 4 * a * c, hh = 0.5 * sqrt(disc) / a, m = -0.5 * b / a; l0 = m + hh; l1 = m - hh; }
-            else { l0 = l1 = NAN; }
+            else if (a != 0) { double ia = 0.5 / a, sq = sqrt(b * b - 4 * a * c); l0 = (sq - b) * ia; l1 = (-b - sq) * ia; }
             double g0 = 2 * sQd + dP; // d . (2 pQ + P) = g0 + 2 l a
-            RT_CONSIDER(l0, -isgn(g0 + 2 * l0 * a));
-            RT_CONSIDER(l1, -isgn(g0 + 2 * l1 * a));
+            s0 = g0 + 2 * l0 * a; s1 = g0 + 2 * l1 * a;
         } else if (shape == SH_TORUS) { // RayToTorus.m:88-159
             V3 ax = ld3(g + 3), x = sp - ld3(g);
             double R1 = g[6], r2 = g[7];
-            double t0 = -dot(x, d) / dot(d, d);
+            double t0 = -dot(x, d);
             V3 xs = x + t0 * d;
-            double X2 = dot(xs, xs), Rb = fabs(R1) + fabs(r2);
-            // the torus lies inside the sphere of radius R1+r2: nothing to solve for rays that miss it or whose
-            // nearest possible hit is beyond the best hit so far
-            bool maybe = (X2 <= Rb * Rb) && (t0 - sqrt(fmax(Rb * Rb - X2, 0.0)) < h.l);
+            double X2 = dot(xs, xs), Rb = fabs(R1) + fabs(r2), w = Rb * Rb - X2;
+            // the torus lies inside the sphere of radius R1+r2 about its centre: nothing to solve for rays that miss
+            // that sphere or whose nearest possible hit lies beyond the best hit so far
+            bool maybe = (w >= 0) && (t0 - sqrt(fmax(w, 0.0)) < h.l);
+            M = 0;
             if (RT_ANY(maybe)) {
                 double xa = dot(xs, ax), da = dot(d, ax), K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
                 double pp = 2 * K - R4 * (1 - da * da), qq = 2 * R4 * xa * da, rr = K * K - R4 * (X2 - xa * xa);
-                double y0, y1, y2, y3;
-                solve_depressed_quartic(pp, qq, rr, y0, y1, y2, y3);
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    double ym = m == 0 ? y0 : (m == 1 ? y1 : (m == 2 ? y2 : y3));
-                    double l_ = maybe ? ym + t0 : NAN;
-                    bool c_ = (l_ > lmin) && (l_ < h.l);
-                    if (RT_ANY(c_)) {
-                        if (c_) {
-                            V3 p_ = sp + l_ * d, xx = p_ - ld3(g);
-                            double xxa = dot(xx, ax); V3 yv = xxa * ax, uu = xx - yv;
-                            double un = sqrt(dot(uu, uu));
-                            V3 nn = (1.0 / r2) * (uu * (1 - R1 / un) + yv);
-                            int o_ = -isgn(dot(d, nn));
-                            if (o_ != 0 && inbounds(G, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; }
-                        }
-                    }
+                Roots4 y = solve_depressed_quartic(pp, qq, rr);
+                l0 = maybe ? y.y0 + t0 : NAN; l1 = maybe ? y.y1 + t0 : NAN; l2 = maybe ? y.y2 + t0 : NAN; l3 = maybe ? y.y3 + t0 : NAN;
+                M = 4;
+            }
+        }
+#pragma unroll 1
+        for (int m = 0; m < M; m++) {
+            double l_ = m == 0 ? l0 : (m == 1 ? l1 : (m == 2 ? l2 : l3));
+            double s_ = m == 0 ? s0 : s1;
+            bool c_ = (l_ > lmin) && (l_ < h.l);
+            if (shape != SH_TORUS) c_ = c_ && (s_ != 0);
+            if (RT_ANY(c_)) {
+                if (c_) {
+                    V3 p_ = sp + l_ * d;
+                    if (shape == SH_TORUS) s_ = dot(d, torus_normal(g, p_));
+                    int o_ = -isgn(s_);
+                    if (o_ != 0 && inbounds(G, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; }
                 }
             }
         }
@@ -286,59 +310,85 @@ RT_HD V3 surface_normal(const double* row, V3 p, V3 d, int orient) {
 //   s0' = hs|cs|^2 + hp|cp|^2,  s1' = hs|cs|^2 - hp|cp|^2,  s2' + i s3' = (s2 + i s3) conj(cs) cp
 // for (cs,cp) = (rs,rp) or (ts,tp), ts = sqrt(|1-|rs|^2|), tp likewise (.py:145-146).  Valid for physical Stokes
 // vectors (s0 >= |polarised part|).
-RT_HD void fresnel(const Ray10& in, V3 nrm, double n1, double n2, double tir, Ray10& refr, Ray10& refl) {
-    Ray10 r = in;
-    r.d = normalized_if(r.d);
-    V3 n = normalized_if(nrm);
-    r.pol = r.pol - dot(r.pol, r.d) * r.d;
-    r.pol = normalized_if(r.pol);
-    refr = r; refl = r; refl.d = -r.d; refl.s0 = refl.s1 = refl.s2 = refl.s3 = 0;
-    V3 md = -r.d;
-    double cos_i = dot(md, n);
-    bool goodhit = cos_i > 0;
-    V3 inorm = cross(md, n);
-    double sin_i = sqrt(dot(inorm, inorm));
-    bool goodint = sin_i > 0;
-    if (goodint) inorm = (1.0 / sin_i) * inorm;
-    double s1 = r.s1, s2 = r.s2, s3 = r.s3, s0 = r.s0;
-    if (goodint) {
-        double c_rot = dot(inorm, r.pol), s_rot = dot(cross(inorm, r.pol), r.d);
-        double c2 = c_rot * c_rot - s_rot * s_rot, sn2 = 2 * c_rot * s_rot;
-        double o1 = s1, o2 = s2;
-        s1 = o1 * c2 - o2 * sn2; s2 = o1 * sn2 + o2 * c2;
-        refr.pol = inorm; refl.pol = inorm; refr.s1 = s1; refr.s2 = s2;
-    }
-    double sin_t = sin_i * n1 / n2, arg = 1 - sin_t * sin_t, cos_t = 0;
+struct FresnelCore {
+    V3 d, n, pol, inorm;          // normalised direction / normal, child polref, interface normal (z of the local basis)
+    double s0, s1, s2, s3;        // Stokes vector rotated into the plane-of-incidence basis
+    double cos_i, sin_i, sin_t, cos_t;
     double Rs, Rp, cr, ci, Ts, Tp, tst;
-    if (isinf(n2)) { Rs = 1; Rp = 1; cr = -1; ci = 0; Ts = 0; Tp = 0; tst = 0; cos_t = 1; }
+    bool goodhit;
+};
+RT_HD void fresnel_core(const Ray10& in, V3 nrm, double n1, double n2, FresnelCore& c) {
+    c.d = normalized_if(in.d);
+    c.n = normalized_if(nrm);
+    V3 pol = in.pol - dot(in.pol, c.d) * c.d;
+    pol = normalized_if(pol);
+    V3 md = -c.d;
+    c.cos_i = dot(md, c.n);
+    c.goodhit = c.cos_i > 0;
+    c.inorm = cross(md, c.n);
+    c.sin_i = sqrt(dot(c.inorm, c.inorm));
+    c.s0 = in.s0; c.s1 = in.s1; c.s2 = in.s2; c.s3 = in.s3; c.pol = pol;
+    if (c.sin_i > 0) {
+        c.inorm = (1.0 / c.sin_i) * c.inorm;
+        double c_rot = dot(c.inorm, pol), s_rot = dot(cross(c.inorm, pol), c.d);
+        double c2 = c_rot * c_rot - s_rot * s_rot, sn2 = 2 * c_rot * s_rot;
+        c.s1 = in.s1 * c2 - in.s2 * sn2; c.s2 = in.s1 * sn2 + in.s2 * c2;
+        c.pol = c.inorm;
+    }
+    c.sin_t = c.sin_i * n1 / n2;
+    double arg = 1 - c.sin_t * c.sin_t;
+    c.cos_t = 0;
+    if (isinf(n2)) { c.Rs = 1; c.Rp = 1; c.cr = -1; c.ci = 0; c.Ts = 0; c.Tp = 0; c.tst = 0; c.cos_t = 1; }
     else if (arg >= 0) {
-        cos_t = sqrt(arg);
-        double rs = (n1 * cos_i - n2 * cos_t) / (n1 * cos_i + n2 * cos_t), rp = -(n1 * cos_t - n2 * cos_i) / (n1 * cos_t + n2 * cos_i);
-        Rs = rs * rs; Rp = rp * rp; cr = rs * rp; ci = 0; Ts = fabs(1 - Rs); Tp = fabs(1 - Rp); tst = sqrt(Ts * Tp);
+        c.cos_t = sqrt(arg);
+        double a1 = n1 * c.cos_i, a2 = n2 * c.cos_t, b1 = n1 * c.cos_t, b2 = n2 * c.cos_i;
+        double rs = (a1 - a2) / (a1 + a2), rp = -(b1 - b2) / (b1 + b2);
+        c.Rs = rs * rs; c.Rp = rp * rp; c.cr = rs * rp; c.ci = 0; c.Ts = fabs(1 - c.Rs); c.Tp = fabs(1 - c.Rp); c.tst = sqrt(c.Ts * c.Tp);
     } else { // total internal reflection: |rs| = |rp| = 1, only the relative phase matters
-        double kap = sqrt(-arg), A = n1 * cos_i, B = n2 * kap, C = n1 * kap, Dd = n2 * cos_i;
+        double kap = sqrt(-arg), A = n1 * c.cos_i, B = n2 * kap, C = n1 * kap, Dd = n2 * c.cos_i;
         double ia = 1.0 / (A * A + B * B), ic = 1.0 / (Dd * Dd + C * C);
         double rsr = (A * A - B * B) * ia, rsi = -2 * A * B * ia, rpr = (Dd * Dd - C * C) * ic, rpi = -2 * C * Dd * ic;
-        Rs = 1; Rp = 1; Ts = 0; Tp = 0; tst = 0;
-        cr = rsr * rpr + rsi * rpi; ci = rsr * rpi - rsi * rpr; // conj(rs) * rp
-        if (!(arg < 0)) { Rs = Rp = cr = ci = NAN; } // NaN input
+        c.Rs = 1; c.Rp = 1; c.Ts = 0; c.Tp = 0; c.tst = 0;
+        c.cr = rsr * rpr + rsi * rpi; c.ci = rsr * rpi - rsi * rpr; // conj(rs) * rp
+        if (!(arg < 0)) { c.Rs = c.Rp = c.cr = c.ci = NAN; } // NaN input
     }
-    if (goodhit) {
-        double hs = 0.5 * (s0 + s1), hp = 0.5 * (s0 - s1);
-        refl.s0 = hs * Rs + hp * Rp; refl.s1 = hs * Rs - hp * Rp; refl.s2 = s2 * cr - s3 * ci; refl.s3 = s2 * ci + s3 * cr;
-        refr.s0 = hs * Ts + hp * Tp; refr.s1 = hs * Ts - hp * Tp; refr.s2 = s2 * tst; refr.s3 = s3 * tst;
-    }
-    V3 ny = cross(n, inorm);
+}
+RT_HD double fresnel_refl_s0(const FresnelCore& c) { return c.goodhit ? 0.5 * (c.s0 + c.s1) * c.Rs + 0.5 * (c.s0 - c.s1) * c.Rp : 0.0; }
+RT_HD double fresnel_refr_s0(const FresnelCore& c) { return c.goodhit ? 0.5 * (c.s0 + c.s1) * c.Ts + 0.5 * (c.s0 - c.s1) * c.Tp : c.s0; }
+// new y axis of the local basis; false if the hit is bad or the incidence normal (no plane of incidence)
+RT_HD bool fresnel_yaxis(const FresnelCore& c, V3& ny) {
+    ny = cross(c.n, c.inorm);
     double nyn = dot(ny, ny);
-    bool goodcut = goodhit && nyn > 0;
-    if (goodcut) {
-        ny = (1.0 / sqrt(nyn)) * ny;
-        refl.d = cos_i * n - sin_i * ny;
-        bool tircut = sin_t >= 1;
-        if (!tircut) refr.d = (-cos_t) * n - sin_t * ny;
-        else if (tir < 0) refr.d = -ny;
-        else { refr.d = refl.d; refr.pol = refl.pol; refr.s0 = refl.s0 * tir; refr.s1 = refl.s1 * tir; refr.s2 = refl.s2 * tir; refr.s3 = refl.s3 * tir; }
+    bool goodcut = c.goodhit && nyn > 0;
+    if (goodcut) ny = (1.0 / sqrt(nyn)) * ny;
+    return goodcut;
+}
+RT_HD void fresnel_reflected(const FresnelCore& c, Ray10& refl) {
+    refl.d = -c.d; refl.pol = c.pol; refl.s0 = refl.s1 = refl.s2 = refl.s3 = 0;
+    if (c.goodhit) {
+        double hs = 0.5 * (c.s0 + c.s1), hp = 0.5 * (c.s0 - c.s1);
+        refl.s0 = hs * c.Rs + hp * c.Rp; refl.s1 = hs * c.Rs - hp * c.Rp; refl.s2 = c.s2 * c.cr - c.s3 * c.ci; refl.s3 = c.s2 * c.ci + c.s3 * c.cr;
     }
+    V3 ny;
+    if (fresnel_yaxis(c, ny)) refl.d = c.cos_i * c.n - c.sin_i * ny;
+}
+RT_HD void fresnel_refracted(const FresnelCore& c, double tir, Ray10& refr) {
+    refr.d = c.d; refr.pol = c.pol; refr.s0 = c.s0; refr.s1 = c.s1; refr.s2 = c.s2; refr.s3 = c.s3;
+    if (c.goodhit) {
+        double hs = 0.5 * (c.s0 + c.s1), hp = 0.5 * (c.s0 - c.s1);
+        refr.s0 = hs * c.Ts + hp * c.Tp; refr.s1 = hs * c.Ts - hp * c.Tp; refr.s2 = c.s2 * c.tst; refr.s3 = c.s3 * c.tst;
+    }
+    V3 ny;
+    if (fresnel_yaxis(c, ny)) {
+        bool tircut = c.sin_t >= 1;
+        if (!tircut) refr.d = (-c.cos_t) * c.n - c.sin_t * ny;
+        else if (tir < 0) refr.d = -ny;
+        else { Ray10 refl; fresnel_reflected(c, refl); refr.d = refl.d; refr.s0 = refl.s0 * tir; refr.s1 = refl.s1 * tir; refr.s2 = refl.s2 * tir; refr.s3 = refl.s3 * tir; }
+    }
+}
+RT_HD void fresnel(const Ray10& in, V3 nrm, double n1, double n2, double tir, Ray10& refr, Ray10& refl) {
+    FresnelCore c; fresnel_core(in, nrm, n1, n2, c);
+    fresnel_refracted(c, tir, refr); fresnel_reflected(c, refl);
 }
 
 // ---------------------------------------------------------------------------------------------- UNIFIED
@@ -369,9 +419,12 @@ RT_HD V3 facet_normal(Rng& g, V3 indir, V3 sn, V3 sx, V3 sy, double sig, int max
 }
 RT_HD void renorm(Ray10& t, double s0) { double f = s0 / t.s0; t.s0 *= f; t.s1 *= f; t.s2 *= f; t.s3 *= f; }
 
-RT_HD Ray10 unified(Rng& g, const Ray10& in, V3 nrm, double n1, double n2, const double* prm, int maxiter) {
+// Out of line on the device: the rough-surface loop needs ~170 VGPRs on its own, which must not set the register
+// budget (occupancy) of the whole bounce kernel.  The generator travels by value; the caller re-aligns its stream to
+// the next Philox block afterwards (rng_align), so nothing has to come back but the ray.
+struct UnifiedOut { Ray10 r; uint32_t idx; };
+RT_COLD UnifiedOut unified(Rng g, Ray10 in, V3 nrm, double n1, double n2, double sig, double pdiff, double c1, double c2, double c3, int maxiter) {
     Ray10 R = in;
-    double sig = prm[0], pdiff = prm[1], c1 = prm[2], c2 = prm[2] + prm[3], c3 = prm[2] + prm[3] + prm[4];
     R.d = normalized_if(R.d);
     V3 N = normalized_if(nrm);
     R.pol = R.pol - dot(R.pol, R.d) * R.d;
@@ -395,19 +448,20 @@ RT_HD Ray10 unified(Rng& g, const Ray10& in, V3 nrm, double n1, double n2, const
         int guard2 = 0;
         while (crossing && guard2++ < 2 * maxiter) {
             if (!second) nuse = facet_normal(g, R.d, N, sx, sy, sig, maxiter);
-            Ray10 refr, refl;
-            fresnel(R, nuse, n1, n2, -1.0, refr, refl);
-            if (second) { renorm(refl, R.s0); R = refl; crossing = false; second = false; continue; }
-            bool reflect_here = rng_uniform(g) > (refr.s0 / (refr.s0 + refl.s0));
+            FresnelCore fc; fresnel_core(R, nuse, n1, n2, fc);
+            const double s0_in = R.s0;
+            if (second) { fresnel_reflected(fc, R); renorm(R, s0_in); crossing = false; second = false; continue; }
+            double t_s0 = fresnel_refr_s0(fc), r_s0 = fresnel_refl_s0(fc);
+            bool reflect_here = rng_uniform(g) > (t_s0 / (t_s0 + r_s0));
             if (!reflect_here) {
-                renorm(refr, R.s0);
-                R = refr; N = -N;
+                fresnel_refracted(fc, -1.0, R); renorm(R, s0_in);
+                N = -N;
                 double t = n1; n1 = n2; n2 = t;
                 insurface = !insurface;
                 crossing = dot(R.d, N) <= 0;
             } else {
                 double roll = rng_uniform(g);
-                if (roll < c1) { renorm(refl, R.s0); R = refl; crossing = dot(R.d, N) <= 0; }
+                if (roll < c1) { fresnel_reflected(fc, R); renorm(R, s0_in); crossing = dot(R.d, N) <= 0; }
                 else {
                     if (roll < c2) nuse = N;
                     else if (roll < c3) nuse = -R.d;
@@ -425,8 +479,9 @@ RT_HD Ray10 unified(Rng& g, const Ray10& in, V3 nrm, double n1, double n2, const
             R.pol = (1.0 / sqrt(dot(t, t))) * t;
         }
     }
-    return R;
+    return UnifiedOut{ R, g.idx };
 }
+RT_HD void rng_align(Rng& g, uint32_t idx) { g.idx = (idx + 1u) & ~1u; } // continue with a fresh Philox block
 
 // ---------------------------------------------------------------------------------------------- Rayleigh
 // MATLAB/Physics/RayleighScattering.m:62-148; lut = rayleigh_azimuth (:55-60), prec = azimuth_precision
@@ -524,7 +579,11 @@ RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
     b.inc = q.r; b.inc.s0 *= trans; b.inc.s1 *= trans; b.inc.s2 *= trans; b.inc.s3 *= trans;
     b.refr = b.inc; b.refr.s0 = b.refr.s1 = b.refr.s2 = b.refr.s3 = 0; b.refl = b.refr;
     if (nor_sc) fresnel(b.inc, sopt, b.n1, b.n2, P.tir, b.refr, b.refl); // :438-439
-    if (uni_sc) b.refl = unified(g, b.inc, b.nmech, b.n1, b.n2, row + 22, P.maxiter); // :443-444
+    if (uni_sc) { // :443-444
+        double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
+        UnifiedOut u = unified(g, b.inc, b.nmech, b.n1, b.n2, row[22], row[23], c1, c2, c3, P.maxiter);
+        b.refl = u.r; rng_align(g, u.idx);
+    }
     if (b.surf_sc) { double f = 1 - absn; b.refr.s0 *= f; b.refr.s1 *= f; b.refr.s2 *= f; b.refr.s3 *= f; b.refl.s0 *= f; b.refl.s1 *= f; b.refl.s2 *= f; b.refl.s3 *= f; } // :447-449
     if (b.ray_sc) b.refl = rayleigh(g, b.inc, G.lut, G.lut_prec); // :452-454
     if (P.flags & FLAG_SINGLE) { // :458-467

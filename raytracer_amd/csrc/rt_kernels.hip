@@ -144,24 +144,23 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* cou
     return base + (unsigned long long)__popcll(act & ((1ull << lane) - 1ull));
 }
 
-__global__ void __launch_bounds__(BLOCK) k_trace(const KArgs a) {
+#ifndef RT_WAVES
+#define RT_WAVES 4
+#endif
+__global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
     extern __shared__ double smem[];
-    // LDS image: surface rows | atoms | tally rows | code | per-step counters
+    // LDS image: surface rows (per-lane gather of the winning surface) | tally rows | per-step counters
     double* s_surf = smem;
-    double* s_atoms = s_surf + a.S * ROW;
-    double* s_tab = s_atoms + a.n_atoms * ATOM;
+    double* s_tab = s_surf + a.S * ROW;
     const int ntab = a.rows_lds * 5 * a.S * 2;
-    uint32_t* s_code = (uint32_t*)(s_tab + ntab);
-    uint32_t* s_live = s_code + ((a.n_code + 1) & ~1);
+    uint32_t* s_live = (uint32_t*)(s_tab + ntab);
     uint32_t* s_scat = s_live + a.P.K;
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
-    for (int i = threadIdx.x; i < a.n_atoms * ATOM; i += BLOCK) s_atoms[i] = a.atoms[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
-    for (int i = threadIdx.x; i < a.n_code; i += BLOCK) s_code[i] = a.code[i];
     for (int i = threadIdx.x; i < 2 * a.P.K; i += BLOCK) s_live[i] = 0u;
     __syncthreads();
 
-    Geom G{ s_surf, s_atoms, s_code, a.S, a.lut, a.lut_prec };
+    Geom G{ (udptr)a.surf, (udptr)a.atoms, (uuptr)a.code, s_surf, a.S, a.lut, a.lut_prec };
     const Prm P = a.P;
     const int lane = lane_id();
     RayState q;
@@ -279,7 +278,7 @@ struct rt_ctx {
     std::vector<double> fin;
     double kernel_ms = 0; int n_launches = 0;
     // options
-    size_t workspace_bytes = (size_t)8 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 16; int blocks_per_cu = 0;
+    size_t workspace_bytes = (size_t)8 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 16; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
 };
 
 static std::string g_init_err;
@@ -328,6 +327,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "refill_min") ctx->refill_min = (int)value;
     else if (k == "blocks_per_cu") ctx->blocks_per_cu = (int)value;
     else if (k == "nodice_chunk") ctx->nodice_chunk = (int64_t)value;
+    else if (k == "lds_budget_kb") ctx->lds_budget = (size_t)(value * 1024);
     else { ctx->err = "rt_set_option: unknown key " + k; return -1; }
     return 0;
 }
@@ -411,18 +411,18 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
     ctx->fin.clear(); if (wantfin) ctx->fin.resize((size_t)n * FIN);
 
-    // ---- LDS budget
+    // ---- LDS budget: surface rows + as many absorption_table rows as fit in lds_budget (the first steps carry almost
+    // all interactions; deeper rows go to global atomics)
     const int n_atoms = ctx->n_atoms, n_code = ctx->n_code;
-    size_t fixed = (size_t)S * ROW * 8 + (size_t)n_atoms * ATOM * 8 + (size_t)((n_code + 1) & ~1) * 4 + (size_t)2 * K * 4;
-    const size_t lds_max = 64 * 1024; // keep two+ workgroups per CU resident
-    if (fixed > lds_max) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
+    size_t fixed = (size_t)S * ROW * 8 + (size_t)2 * K * 4;
+    const size_t lds_max = ctx->lds_budget;
     size_t rowb = (size_t)5 * S * 2 * 8;
-    int rows_lds = (int)std::min<size_t>((size_t)K, (lds_max - fixed) / rowb);
+    int rows_lds = fixed + rowb <= lds_max ? (int)std::min<size_t>((size_t)K, (lds_max - fixed) / rowb) : 0;
     size_t lds = fixed + (size_t)rows_lds * rowb;
+    if (lds > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
     CK(hipFuncSetAttribute((const void*)k_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int bpc = ctx->blocks_per_cu;
     if (bpc <= 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace, BLOCK, lds) != hipSuccess || nb < 1) nb = 1; bpc = nb > 8 ? 8 : nb; }
-
     // ---- chunking
     const size_t W = ctx->workspace_bytes;
     const size_t rec_bytes = (size_t)REC * 8 + 4 + 8 + 8 + 4;

@@ -20,7 +20,7 @@ static void tally(std::vector<double>& t, int S, int k, int cat, int smix, int b
 
 extern "C" int hs_trace(const double* sp, const double* rays, int64_t n, const double* table, int S, const double* atoms, const uint32_t* code,
                         const double* lut, int lut_n, const Params* prm, Result** out) {
-    Geom G{ table, atoms, code, S, lut, lut_n - 1 };
+    Geom G{ table, atoms, code, table, S, lut, lut_n - 1 };
     Prm P; P.K = prm->max_scatters; P.flags = prm->flags; P.compat = prm->compat; P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
     P.base = (prm->compat & COMPAT_PY_INDEX) ? 0 : 1; P.min_travel = prm->min_travel_length; P.thrA = prm->follow_threshold[0]; P.thrB = prm->follow_threshold[1];
     P.tir = prm->tir_handling; P.key0 = (uint32_t)prm->seed; P.key1 = (uint32_t)(prm->seed >> 32);
