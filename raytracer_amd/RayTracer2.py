@@ -218,7 +218,17 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     want_rec = bool(full_output or output_raytable)
     flags = (_lib.FLAG_FULL_OUTPUT if want_rec else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | (_lib.FLAG_FINAL_ROWS if return_final else 0)
     prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
-    c._check(c.L.rt_trace(c.h, _dp(sp), _dp(ry), n, C.byref(prm)))
+    chunk = None
+    for attempt in range(8):
+        try:
+            c._check(c.L.rt_trace(c.h, _dp(sp), _dp(ry), n, C.byref(prm)))
+            break
+        except _lib.RayTracerLibraryError as e:
+            # ray-splitting mode cannot bound its queue/record growth in advance: on overflow retry with smaller passes
+            if getattr(e, "code", 0) != -3 or singlechild or attempt == 7:
+                raise
+            chunk = max(256, (chunk if chunk is not None else min(n, 1 << 20)) // 4)
+            c.set_option("nodice_chunk", chunk)
     res = c.results(want_rec, return_final, n)
     ns = res["num_steps"]
     base = 0 if (COMPAT[compat] & _lib.COMPAT_PY_INDEX) else 1

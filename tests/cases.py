@@ -142,3 +142,27 @@ def unpack_interfaces(z, prefix="s"):
             setattr(ri, f, z["%s%d_%s" % (prefix, k, f)])
         out.append(ri)
     return out
+
+
+def mixed_geometry(cls=Surf):
+    """Small closed scene exercising every shape and surface type: a torus and a quadric cone inside an absorbing sphere,
+    a diffuse disk, a retro disk, a UNIFIED rough cylinder, with bulk absorption and Rayleigh scattering in the fill."""
+    def mk(desc, shape, pl, inb, no, ni, st, ab, **kw):
+        s = cls(); s.description = desc; s.shape = shape; s.param_list = pl; s.inbounds_function = inb
+        s.n_outside = no; s.n_inside = ni; s.surface_type = st; s.absorption = ab
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+    fill = dict(abslength_inside=80.0, rayleigh_inside=25.0, abslength_outside=np.inf, rayleigh_outside=np.inf)
+    sl = []
+    sl.append(mk('outer sphere', 'sphere', [np.array([0, 0, 0.]), 30.], lambda p: np.reshape(p[:, 2, :] > -1e9, (p.shape[0], -1)), np.inf, 1.33, 'normal', 1.0, **fill))
+    sl.append(mk('glass torus', 'torus', [np.array([0, 0, 4.]), np.array([0, 0, 1.]), 8., 2.], lambda p: np.reshape(p[:, 2, :] > -1e9, (p.shape[0], -1)), 1.33, 1.5, 'normal', 0.0,
+                 abslength_outside=80.0, rayleigh_outside=25.0, abslength_inside=200.0, rayleigh_inside=np.inf))
+    Q = np.diag([1., 1., -0.25]); Pv = np.array([0, 0, -5.]); R = -25.0  # cone x^2+y^2 = (z+10)^2/4
+    sl.append(mk('mirror cone', 'quadsurface', [Q, Pv, R], lambda p: np.reshape((p[:, 2, :] > -9.5) & (p[:, 2, :] < -4), (p.shape[0], -1)), 1.6, 1.33, 'normal', 0.2, **fill))
+    sl.append(mk('diffuse disk', 'plane', [np.array([0, 0, 15.]), np.array([0, 0, 1.])], lambda p: np.reshape((p[:, 0, :] ** 2 + p[:, 1, :] ** 2) < 10000, (p.shape[0], -1)), np.inf, 1.33, 'diffuse', 0.3, **fill))
+    sl.append(mk('retro disk', 'plane', [np.array([0, 0, -15.]), np.array([0, 0, 1.])], lambda p: np.reshape((p[:, 0, :] ** 2 + p[:, 1, :] ** 2) < 10000, (p.shape[0], -1)), 1.33, np.inf, 'retro', 0.1,
+                 abslength_outside=80.0, rayleigh_outside=25.0, abslength_inside=np.inf, rayleigh_inside=np.inf))
+    sl.append(mk('rough cylinder', 'cylinder', [np.array([0, 0, 0.]), np.array([.1, 0, 1.]), 20.], lambda p: np.reshape((p[:, 2, :] > -12) & (p[:, 2, :] <= 12), (p.shape[0], -1)), 1.5, 1.33, 'unified', 0.05,
+                 unifiedparams=[.15, .7, .3, .2, .1], **fill))
+    return sl
