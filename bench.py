@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rays", type=int, default=1 << 23, help="rays per step per GPU")
+    ap.add_argument("--rays", type=int, default=1 << 25, help="rays per step per GPU")
     ap.add_argument("--workload", default="sbc_full_mc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2024)

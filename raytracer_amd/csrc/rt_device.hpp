@@ -64,7 +64,10 @@ struct Ray10 { V3 d, pol; double s0, s1, s2, s3; };
 #endif
 typedef const RT_UNIFORM double* udptr;
 typedef const RT_UNIFORM uint32_t* uuptr;
-struct Geom { udptr usurf; udptr uatoms; uuptr ucode; const double* surf; int S; const double* lut; int lut_prec; };
+// smeta: 4 uint32 per surface {shape, surface type, bounds offset, bounds length}; ameta: 4 uint32 per atom
+// {kind, cmp (0 <, 1 <=, 2 ==, 3 !=), axis, negate}.  uatoms is the device form of the atoms: '>' and '>=' atoms are
+// stored negated as '<' / '<=' (coordinate atoms keep a negate flag instead), see build_device_tables().
+struct Geom { udptr usurf; udptr uatoms; uuptr ucode; uuptr smeta; uuptr ameta; const double* surf; int S; const double* lut; int lut_prec; };
 struct Prm {
     int K, flags, compat, maxiter, base;
     double min_travel, thrA, thrB, tir;
@@ -120,13 +123,14 @@ RT_HD bool inbounds(const Geom& G, int off, int len, V3 p) {
         uint32_t ins = G.ucode[off + i], op = ins >> 24, arg = ins & 0xFFFFFFu, b;
         if (op == 1) {
             udptr a = G.uatoms + (size_t)arg * ATOM;
-            int kind = (int)a[0], cmp = (int)a[1];
+            uuptr am = G.ameta + (size_t)arg * 4;
+            const uint32_t kind = am[0], cmp = am[1];
             double rhs = a[2], v;
-            if (kind == 3) { int ax = (int)a[3]; v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z); }
+            if (kind == 3) { uint32_t ax = am[2]; v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z); if (am[3]) v = -v; }
             else if (kind == 1) v = a[9] * p.x + a[10] * p.y + a[11] * p.z;
             else if (kind == 0) v = a[3] * p.x * p.x + a[4] * p.y * p.y + a[5] * p.z * p.z + a[6] * p.x * p.y + a[7] * p.x * p.z + a[8] * p.y * p.z + a[9] * p.x + a[10] * p.y + a[11] * p.z;
             else v = atan2_atom(a[3] * p.x + a[4] * p.y + a[5] * p.z + a[6], a[7] * p.x + a[8] * p.y + a[9] * p.z + a[10]);
-            b = cmp == 0 ? (v < rhs) : cmp == 1 ? (v <= rhs) : cmp == 2 ? (v > rhs) : cmp == 3 ? (v >= rhs) : cmp == 4 ? (v == rhs) : (v != rhs);
+            b = cmp == 0 ? (v < rhs) : cmp == 1 ? (v <= rhs) : cmp == 2 ? (v == rhs) : (v != rhs);
             st = (st << 1) | b;
         } else if (op == 2) { b = (st & 1u) & ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
         else if (op == 3) { b = (st & 1u) | ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
@@ -136,6 +140,35 @@ RT_HD bool inbounds(const Geom& G, int off, int len, V3 p) {
         else if (op == 7) { b = (st & 1u) ^ ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
     }
     return (st & 1u) != 0;
+}
+
+} // namespace rt
+#include <vector>
+namespace rt {
+#if defined(__HIPCC__)
+#define RT_HOST __host__
+#else
+#define RT_HOST
+#endif
+// Host: public tables of include/rt_mi355x.h -> device form (integer metadata as integers, every ordering atom as
+// '<' or '<=').  Negating an atom is exact: -(v) < -(rhs) <=> v > rhs in IEEE arithmetic, NaN included (both false).
+RT_HOST static inline void build_device_tables(const double* table, int S, const double* atoms, int nA, std::vector<double>& datoms, std::vector<uint32_t>& smeta, std::vector<uint32_t>& ameta) {
+    smeta.resize((size_t)(S > 0 ? S : 1) * 4); ameta.assign((size_t)(nA > 0 ? nA : 1) * 4, 0u); datoms.assign(atoms, atoms + (size_t)nA * ATOM);
+    if (datoms.empty()) datoms.resize(ATOM, 0.0);
+    for (int s = 0; s < S; s++) { const double* r = table + (size_t)s * ROW; smeta[4 * s] = (uint32_t)(int)r[0]; smeta[4 * s + 1] = (uint32_t)(int)r[1]; smeta[4 * s + 2] = (uint32_t)(int)r[27]; smeta[4 * s + 3] = (uint32_t)(int)r[28]; }
+    for (int a = 0; a < nA; a++) {
+        double* d = &datoms[(size_t)a * ATOM];
+        int kind = (int)d[0], cmp = (int)d[1];
+        uint32_t neg = 0, dc;
+        if (cmp == 2 || cmp == 3) { // > , >=  ->  negated < , <=
+            neg = 1; d[2] = -d[2];
+            if (kind == 0 || kind == 1) for (int j = 3; j < ATOM; j++) d[j] = -d[j];
+            // kind 2 (atan2): atan2 is odd in its first argument: -atan2(y,x) = atan2(-y,x)
+            if (kind == 2) for (int j = 3; j <= 6; j++) d[j] = -d[j];
+            dc = (cmp == 2) ? 0u : 1u;
+        } else dc = (cmp == 0) ? 0u : (cmp == 1) ? 1u : (cmp == 4) ? 2u : 3u;
+        ameta[4 * a] = (uint32_t)kind; ameta[4 * a + 1] = dc; ameta[4 * a + 2] = (kind == 3) ? (uint32_t)(int)d[3] : 0u; ameta[4 * a + 3] = (kind == 3) ? neg : 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- nearest hit
@@ -211,7 +244,8 @@ RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, Hit&
     for (int n = 0; n < G.S; n++) {
         udptr row = G.usurf + n * ROW;
         udptr g = row + 2;
-        const int shape = (int)row[0], boff = (int)row[27], blen = (int)row[28];
+        uuptr sm = G.smeta + 4 * n;
+        const int shape = (int)sm[0], boff = (int)sm[2], blen = (int)sm[3];
         const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
         double l0 = NAN, l1 = NAN, l2 = NAN, l3 = NAN, s0 = 0, s1 = 0; // s = d . (outward normal) up to a positive factor
         int M = 2;
@@ -274,7 +308,12 @@ RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, Hit&
             if (RT_ANY(c_)) {
                 if (c_) {
                     V3 p_ = sp + l_ * d;
-                    if (shape == SH_TORUS) s_ = dot(d, torus_normal(g, p_));
+                    if (shape == SH_TORUS) { // sign of d . normal; normal = (1/r2)(u (1 - R1/|u|) + y): scaled by |u| r2^2 > 0
+                        V3 ax = ld3(g + 3), xx = p_ - ld3(g);
+                        double xxa = dot(xx, ax); V3 yv = xxa * ax, uu = xx - yv;
+                        double un = sqrt(dot(uu, uu));
+                        s_ = dot(d, (un - g[6]) * uu + un * yv) * g[7];
+                    }
                     int o_ = -isgn(s_);
                     if (o_ != 0 && inbounds(G, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; }
                 }

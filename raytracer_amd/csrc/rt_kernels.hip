@@ -61,7 +61,7 @@ struct KArgs {
     double* table; unsigned long long* n_live; unsigned long long* n_scat;
     int* overflow;
     // geometry
-    const double* surf; int S; const double* atoms; int n_atoms; const uint32_t* code; int n_code; const double* lut; int lut_prec;
+    const double* surf; int S; const double* atoms; int n_atoms; const uint32_t* code; int n_code; const uint32_t* smeta; const uint32_t* ameta; const double* lut; int lut_prec;
     Prm P;
     int rows_lds;           // absorption_table rows kept in LDS (the rest goes straight to global atomics)
     int refill_min;         // refill when at least this many lanes of the wave are idle (or all are)
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
     for (int i = threadIdx.x; i < 2 * a.P.K; i += BLOCK) s_live[i] = 0u;
     __syncthreads();
 
-    Geom G{ (udptr)a.surf, (udptr)a.atoms, (uuptr)a.code, s_surf, a.S, a.lut, a.lut_prec };
+    Geom G{ (udptr)a.surf, (udptr)a.atoms, (uuptr)a.code, (uuptr)a.smeta, (uuptr)a.ameta, s_surf, a.S, a.lut, a.lut_prec };
     const Prm P = a.P;
     const int lane = lane_id();
     RayState q;
@@ -266,7 +266,8 @@ struct rt_ctx {
     int device = 0; hipStream_t stream = nullptr; int n_cu = 0; size_t hbm = 0; std::string name;
     std::string err;
     // geometry
-    double* d_surf = nullptr; double* d_atoms = nullptr; uint32_t* d_code = nullptr; double* d_lut = nullptr;
+    double* d_surf = nullptr; double* d_atoms = nullptr; uint32_t* d_code = nullptr; uint32_t* d_smeta = nullptr; uint32_t* d_ameta = nullptr; double* d_lut = nullptr;
+    bool has_rayleigh = false;
     int S = 0, n_atoms = 0, n_code = 0, lut_n = 0;
     // persistent small buffers
     unsigned long long* d_counters = nullptr; // head, tail, rec_count + overflow(int)
@@ -278,7 +279,7 @@ struct rt_ctx {
     std::vector<double> fin;
     double kernel_ms = 0; int n_launches = 0;
     // options
-    size_t workspace_bytes = (size_t)8 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 16; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
+    size_t workspace_bytes = (size_t)8 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
 };
 
 static std::string g_init_err;
@@ -308,7 +309,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
 extern "C" void rt_free(rt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps);
+    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); hipFree(ctx->d_smeta); hipFree(ctx->d_ameta); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -357,13 +358,21 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
         if (kind == 3) { int ax = (int)atoms[(size_t)i * ATOM + 3]; if (ax < 0 || ax > 2) { ctx->err = "rt_set_surfaces: bad coordinate atom"; return -1; } }
     }
     CK(hipSetDevice(ctx->device));
-    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); ctx->d_surf = ctx->d_atoms = nullptr; ctx->d_code = nullptr;
+    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); hipFree(ctx->d_smeta); hipFree(ctx->d_ameta);
+    ctx->d_surf = ctx->d_atoms = nullptr; ctx->d_code = nullptr; ctx->d_smeta = ctx->d_ameta = nullptr;
+    std::vector<double> datoms; std::vector<uint32_t> smeta, ameta;
+    build_device_tables(table, n_surf, atoms, n_atoms, datoms, smeta, ameta);
     CK(hipMalloc(&ctx->d_surf, sizeof(double) * (size_t)n_surf * ROW));
-    CK(hipMalloc(&ctx->d_atoms, sizeof(double) * (size_t)(n_atoms > 0 ? n_atoms : 1) * ATOM));
+    CK(hipMalloc(&ctx->d_atoms, sizeof(double) * datoms.size()));
     CK(hipMalloc(&ctx->d_code, sizeof(uint32_t) * (size_t)(n_code > 0 ? n_code : 1)));
+    CK(hipMalloc(&ctx->d_smeta, 4 * smeta.size())); CK(hipMalloc(&ctx->d_ameta, 4 * ameta.size()));
     CK(hipMemcpy(ctx->d_surf, table, sizeof(double) * (size_t)n_surf * ROW, hipMemcpyHostToDevice));
-    if (n_atoms) CK(hipMemcpy(ctx->d_atoms, atoms, sizeof(double) * (size_t)n_atoms * ATOM, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_atoms, datoms.data(), sizeof(double) * datoms.size(), hipMemcpyHostToDevice));
     if (n_code) CK(hipMemcpy(ctx->d_code, code, sizeof(uint32_t) * (size_t)n_code, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_smeta, smeta.data(), 4 * smeta.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_ameta, ameta.data(), 4 * ameta.size(), hipMemcpyHostToDevice));
+    ctx->has_rayleigh = false;
+    for (int s = 0; s < n_surf; s++) if (table[(size_t)s * ROW + 20] < INFINITY || table[(size_t)s * ROW + 21] < INFINITY) ctx->has_rayleigh = true;
     ctx->S = n_surf; ctx->n_atoms = n_atoms; ctx->n_code = n_code;
     return 0;
 }
@@ -397,8 +406,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     CK(hipSetDevice(ctx->device));
     const int S = ctx->S;
     const bool full = prm->flags & RT_FLAG_FULL_OUTPUT, single = prm->flags & RT_FLAG_SINGLECHILD, wantfin = prm->flags & RT_FLAG_FINAL_ROWS;
-    bool has_rayleigh = false;
-    { std::vector<double> t((size_t)S * ROW); CK(hipMemcpy(t.data(), ctx->d_surf, t.size() * 8, hipMemcpyDeviceToHost)); for (int s = 0; s < S; s++) if (t[(size_t)s * ROW + 20] < INFINITY || t[(size_t)s * ROW + 21] < INFINITY) has_rayleigh = true; }
+    const bool has_rayleigh = ctx->has_rayleigh;
     if (has_rayleigh && !ctx->d_lut) { ctx->err = "rt_trace: geometry has finite Rayleigh lengths but no azimuth table was set (rt_set_rayleigh_lut)"; return -1; }
 
     // ---- per-call device state
@@ -450,7 +458,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (wantfin) CK(hipMalloc(&b_fin.p, (size_t)FIN * 8 * (size_t)chunk));
 
     KArgs a; memset(&a, 0, sizeof a);
-    a.surf = ctx->d_surf; a.S = S; a.atoms = ctx->d_atoms; a.n_atoms = n_atoms; a.code = ctx->d_code; a.n_code = n_code;
+    a.surf = ctx->d_surf; a.S = S; a.atoms = ctx->d_atoms; a.n_atoms = n_atoms; a.code = ctx->d_code; a.n_code = n_code; a.smeta = ctx->d_smeta; a.ameta = ctx->d_ameta;
     a.lut = ctx->d_lut; a.lut_prec = ctx->lut_n > 0 ? ctx->lut_n - 1 : 1;
     a.P.K = K; a.P.flags = prm->flags; a.P.compat = prm->compat; a.P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
     a.P.base = (prm->compat & RT_COMPAT_PY_INDEX) ? 0 : 1; a.P.min_travel = prm->min_travel_length; a.P.thrA = prm->follow_threshold[0]; a.P.thrB = prm->follow_threshold[1];
