@@ -14,6 +14,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifndef RT_HD
 #define RT_HD __host__ __device__ __forceinline__
@@ -52,6 +53,9 @@ RT_HD V3 normalized_if(V3 a) { double n = dot(a, a); if (n > 0) { double s = 1.0
 RT_HD int isgn(double x) { return (x > 0) - (x < 0); }
 
 struct Ray10 { V3 d, pol; double s0, s1, s2, s3; };
+// field-wise selects: a ?: over struct lvalues selects an address, which keeps both structs in (scratch) memory
+RT_HD V3 sel(bool c, V3 a, V3 b) { return { c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z }; }
+RT_HD Ray10 sel(bool c, const Ray10& a, const Ray10& b) { return { sel(c, a.d, b.d), sel(c, a.pol, b.pol), c ? a.s0 : b.s0, c ? a.s1 : b.s1, c ? a.s2 : b.s2, c ? a.s3 : b.s3 }; }
 
 // Wave-uniform data (surface rows walked by the surface loop, bounds atoms and code) is read through the constant
 // address space: with a uniform index hipcc then emits scalar loads (s_load into SGPRs, scalar cache) instead of
@@ -64,10 +68,9 @@ struct Ray10 { V3 d, pol; double s0, s1, s2, s3; };
 #endif
 typedef const RT_UNIFORM double* udptr;
 typedef const RT_UNIFORM uint32_t* uuptr;
-// smeta: 4 uint32 per surface {shape, surface type, bounds offset, bounds length}; ameta: 4 uint32 per atom
-// {kind, cmp (0 <, 1 <=, 2 ==, 3 !=), axis, negate}.  uatoms is the device form of the atoms: '>' and '>=' atoms are
-// stored negated as '<' / '<=' (coordinate atoms keep a negate flag instead), see build_device_tables().
-struct Geom { udptr usurf; udptr uatoms; uuptr ucode; uuptr smeta; uuptr ameta; const double* surf; int S; const double* lut; int lut_prec; };
+// smeta: 4 uint32 per surface {shape, surface type, first bounds record, number of bounds records}; urec: the bounds
+// programs in device form, one 64-byte record per step (see build_device_tables()).
+struct Geom { udptr usurf; udptr urec; uuptr smeta; const double* surf; int S; const double* lut; int lut_prec; };
 struct Prm {
     int K, flags, compat, maxiter, base;
     double min_travel, thrA, thrB, tir;
@@ -111,33 +114,58 @@ RT_HD uint32_t path_hash(uint32_t h, int step, int reflected) {
 // ---------------------------------------------------------------------------------------------- bounds program
 // include/rt_mi355x.h "Bounds program"; replaces surface.inbounds_function (python/surface.py:19-32,
 // called at python/RayTracer2.py:316).  The program is the same for every lane: control flow is wave-uniform.
+//
+// Device form.  The public program (postfix code words that index a separate atom table) costs three dependent
+// scalar loads per atom (code word -> atom -> next code word), and the bounds test sits on the critical path of every
+// candidate hit, so build_device_tables() flattens it into self-contained 64-byte records {meta, rhs, c0..c5}: one
+// scalar load per step, at an address known before the previous step has been looked at (the next record is
+// requested while the current one is evaluated).  meta (low 32 bits of the first double):
+//   bits 0-3 kind, 4-5 comparison (0 <, 1 <=, 2 ==, 3 !=), 6-7 axis, 8 negate, 9 add the accumulator, 10 push the
+//   comparison result, 12-15 number of trailing stack operations, 16-30 those operations (3 bits each).
+// Every ordering atom is stored as '<' or '<=' ('>' and '>=' are negated: -(v) < -(rhs) <=> v > rhs in IEEE
+// arithmetic, NaN included, both false).
+enum { BK_COORD = 0, BK_LIN = 1, BK_QDIAG = 2, BK_ACCX = 3, BK_ACC4 = 4, BK_ATAN2 = 5, BK_CONST = 6, BK_NONE = 7 };
+constexpr int BREC = 8; // doubles per record
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __noinline__ double atan2_atom(double y, double x) { return atan2(y, x); } // rare: keep its registers out of the hot loop
 #else
 static inline double atan2_atom(double y, double x) { return atan2(y, x); }
 #endif
+struct BRec { double w[BREC]; };
+RT_HD BRec brec_load(udptr r) { BRec b; for (int j = 0; j < BREC; j++) b.w[j] = r[j]; return b; } // one 64-byte scalar load
 RT_HD bool inbounds(const Geom& G, int off, int len, V3 p) {
     if (len == 0) return true;
     uint32_t st = 0;
+    double acc = 0;
+    udptr r = G.urec + (size_t)off * BREC;
+    BRec nxt = brec_load(r);
     for (int i = 0; i < len; i++) {
-        uint32_t ins = G.ucode[off + i], op = ins >> 24, arg = ins & 0xFFFFFFu, b;
-        if (op == 1) {
-            udptr a = G.uatoms + (size_t)arg * ATOM;
-            uuptr am = G.ameta + (size_t)arg * 4;
-            const uint32_t kind = am[0], cmp = am[1];
-            double rhs = a[2], v;
-            if (kind == 3) { uint32_t ax = am[2]; v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z); if (am[3]) v = -v; }
-            else if (kind == 1) v = a[9] * p.x + a[10] * p.y + a[11] * p.z;
-            else if (kind == 0) v = a[3] * p.x * p.x + a[4] * p.y * p.y + a[5] * p.z * p.z + a[6] * p.x * p.y + a[7] * p.x * p.z + a[8] * p.y * p.z + a[9] * p.x + a[10] * p.y + a[11] * p.z;
-            else v = atan2_atom(a[3] * p.x + a[4] * p.y + a[5] * p.z + a[6], a[7] * p.x + a[8] * p.y + a[9] * p.z + a[10]);
-            b = cmp == 0 ? (v < rhs) : cmp == 1 ? (v <= rhs) : cmp == 2 ? (v == rhs) : (v != rhs);
+        const BRec c = nxt;
+        r += BREC;
+        if (i + 1 < len) nxt = brec_load(r); // in flight while this record is evaluated
+        uint32_t m; { uint64_t u; memcpy(&u, &c.w[0], 8); m = (uint32_t)u; }
+        const uint32_t kind = m & 15u;
+        const double rhs = c.w[1];
+        double v;
+        if (kind == BK_COORD) { uint32_t ax = (m >> 6) & 3u; v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z); if (m & 256u) v = -v; }
+        else if (kind == BK_LIN) v = c.w[2] * p.x + c.w[3] * p.y + c.w[4] * p.z;
+        else if (kind == BK_QDIAG) v = c.w[2] * p.x * p.x + c.w[3] * p.y * p.y + c.w[4] * p.z * p.z + c.w[5] * p.x + c.w[6] * p.y + c.w[7] * p.z;
+        else if (kind == BK_ACCX) { acc = c.w[2] * p.x * p.y + c.w[3] * p.x * p.z + c.w[4] * p.y * p.z; v = 0; }
+        else if (kind == BK_ACC4) { acc = c.w[2] * p.x + c.w[3] * p.y + c.w[4] * p.z + c.w[5]; v = 0; }
+        else if (kind == BK_ATAN2) { v = atan2_atom(acc, c.w[2] * p.x + c.w[3] * p.y + c.w[4] * p.z + c.w[5]); acc = 0; }
+        else v = 0; // BK_CONST: 0 < rhs
+        if (m & 512u) { v += acc; acc = 0; }
+        if (m & 1024u) {
+            const uint32_t cmp = (m >> 4) & 3u;
+            uint32_t b = cmp == 0 ? (v < rhs) : cmp == 1 ? (v <= rhs) : cmp == 2 ? (v == rhs) : (v != rhs);
             st = (st << 1) | b;
-        } else if (op == 2) { b = (st & 1u) & ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
-        else if (op == 3) { b = (st & 1u) | ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
-        else if (op == 4) st ^= 1u;
-        else if (op == 5) st = (st << 1) | 1u;
-        else if (op == 6) st = (st << 1);
-        else if (op == 7) { b = (st & 1u) ^ ((st >> 1) & 1u); st = ((st >> 2) << 1) | b; }
+        }
+        uint32_t ops = m >> 16;
+        for (uint32_t k = (m >> 12) & 15u; k > 0; k--, ops >>= 3) {
+            const uint32_t op = ops & 7u, t0 = st & 1u, t1 = (st >> 1) & 1u;
+            if (op == 4) st ^= 1u;
+            else st = ((st >> 2) << 1) | (op == 2 ? (t0 & t1) : op == 3 ? (t0 | t1) : (t0 ^ t1));
+        }
     }
     return (st & 1u) != 0;
 }
@@ -150,25 +178,58 @@ namespace rt {
 #else
 #define RT_HOST
 #endif
-// Host: public tables of include/rt_mi355x.h -> device form (integer metadata as integers, every ordering atom as
-// '<' or '<=').  Negating an atom is exact: -(v) < -(rhs) <=> v > rhs in IEEE arithmetic, NaN included (both false).
-RT_HOST static inline void build_device_tables(const double* table, int S, const double* atoms, int nA, std::vector<double>& datoms, std::vector<uint32_t>& smeta, std::vector<uint32_t>& ameta) {
-    smeta.resize((size_t)(S > 0 ? S : 1) * 4); ameta.assign((size_t)(nA > 0 ? nA : 1) * 4, 0u); datoms.assign(atoms, atoms + (size_t)nA * ATOM);
-    if (datoms.empty()) datoms.resize(ATOM, 0.0);
-    for (int s = 0; s < S; s++) { const double* r = table + (size_t)s * ROW; smeta[4 * s] = (uint32_t)(int)r[0]; smeta[4 * s + 1] = (uint32_t)(int)r[1]; smeta[4 * s + 2] = (uint32_t)(int)r[27]; smeta[4 * s + 3] = (uint32_t)(int)r[28]; }
-    for (int a = 0; a < nA; a++) {
-        double* d = &datoms[(size_t)a * ATOM];
-        int kind = (int)d[0], cmp = (int)d[1];
-        uint32_t neg = 0, dc;
-        if (cmp == 2 || cmp == 3) { // > , >=  ->  negated < , <=
-            neg = 1; d[2] = -d[2];
-            if (kind == 0 || kind == 1) for (int j = 3; j < ATOM; j++) d[j] = -d[j];
-            // kind 2 (atan2): atan2 is odd in its first argument: -atan2(y,x) = atan2(-y,x)
-            if (kind == 2) for (int j = 3; j <= 6; j++) d[j] = -d[j];
-            dc = (cmp == 2) ? 0u : 1u;
-        } else dc = (cmp == 0) ? 0u : (cmp == 1) ? 1u : (cmp == 4) ? 2u : 3u;
-        ameta[4 * a] = (uint32_t)kind; ameta[4 * a + 1] = dc; ameta[4 * a + 2] = (kind == 3) ? (uint32_t)(int)d[3] : 0u; ameta[4 * a + 3] = (kind == 3) ? neg : 0u;
+// Host: public tables of include/rt_mi355x.h -> device form: smeta (integer metadata as integers) and the bounds
+// records described above.
+RT_HOST static inline void build_device_tables(const double* table, int S, const double* atoms, int nA, const uint32_t* code, std::vector<double>& recs, std::vector<uint32_t>& smeta) {
+    (void)nA;
+    smeta.resize((size_t)(S > 0 ? S : 1) * 4); recs.clear();
+    auto emit = [&](uint32_t meta, double rhs, const double* c, int nc) {
+        size_t at = recs.size(); recs.resize(at + BREC, 0.0);
+        memcpy(&recs[at], &meta, 4); recs[at + 1] = rhs;
+        for (int j = 0; j < nc; j++) recs[at + 2 + j] = c[j];
+    };
+    for (int s = 0; s < S; s++) {
+        const double* r = table + (size_t)s * ROW;
+        const int off = (int)r[27], len = (int)r[28];
+        const size_t first = recs.size() / BREC;
+        long last = -1; // record that can still take trailing stack operations
+        for (int i = 0; i < len; i++) {
+            const uint32_t ins = code[off + i], op = ins >> 24, arg = ins & 0xFFFFFFu;
+            if (op == 1) {
+                const double* a = atoms + (size_t)arg * ATOM;
+                const int kind = (int)a[0], cmp = (int)a[1];
+                const bool neg = (cmp == 2 || cmp == 3); // > , >=  ->  negated < , <=
+                const double sg = neg ? -1.0 : 1.0, rhs = sg * a[2];
+                const uint32_t dc = neg ? (cmp == 2 ? 0u : 1u) : (cmp == 0 ? 0u : cmp == 1 ? 1u : cmp == 4 ? 2u : 3u);
+                const uint32_t push = 1024u | (dc << 4);
+                if (kind == 3) emit(BK_COORD | push | ((uint32_t)(int)a[3] << 6) | (neg ? 256u : 0u), rhs, nullptr, 0);
+                else if (kind == 1) { double c[3] = { sg * a[9], sg * a[10], sg * a[11] }; emit(BK_LIN | push, rhs, c, 3); }
+                else if (kind == 0) {
+                    const bool cross = a[6] != 0 || a[7] != 0 || a[8] != 0;
+                    if (cross) { double c[3] = { sg * a[6], sg * a[7], sg * a[8] }; emit(BK_ACCX, 0.0, c, 3); }
+                    double c[6] = { sg * a[3], sg * a[4], sg * a[5], sg * a[9], sg * a[10], sg * a[11] };
+                    emit(BK_QDIAG | push | (cross ? 512u : 0u), rhs, c, 6);
+                } else { // atan2 is odd in its first argument: -atan2(y,x) = atan2(-y,x)
+                    double cy[4] = { sg * a[3], sg * a[4], sg * a[5], sg * a[6] }, cx[4] = { a[7], a[8], a[9], a[10] };
+                    emit(BK_ACC4, 0.0, cy, 4); emit(BK_ATAN2 | push, rhs, cx, 4);
+                }
+                last = (long)(recs.size() / BREC) - 1;
+            } else if (op == 5 || op == 6) {
+                emit(BK_CONST | 1024u, op == 5 ? 1.0 : 0.0, nullptr, 0); // pushes (0 < rhs)
+                last = (long)(recs.size() / BREC) - 1;
+            } else if (op == 2 || op == 3 || op == 4 || op == 7) {
+                uint32_t meta = 0;
+                if (last >= 0) memcpy(&meta, &recs[(size_t)last * BREC], 4);
+                if (last < 0 || ((meta >> 12) & 15u) >= 5u) { emit(BK_NONE, 0.0, nullptr, 0); last = (long)(recs.size() / BREC) - 1; meta = BK_NONE; }
+                const uint32_t k = (meta >> 12) & 15u;
+                meta = (meta & ~(15u << 12)) | ((k + 1) << 12) | (op << (16 + 3 * k));
+                memcpy(&recs[(size_t)last * BREC], &meta, 4);
+            }
+        }
+        smeta[4 * s] = (uint32_t)(int)r[0]; smeta[4 * s + 1] = (uint32_t)(int)r[1];
+        smeta[4 * s + 2] = (uint32_t)first; smeta[4 * s + 3] = (uint32_t)(recs.size() / BREC - first);
     }
+    if (recs.empty()) recs.resize(BREC, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------- nearest hit
@@ -177,7 +238,11 @@ struct Hit { double l; int surf; int orient; };
 // depressed quartic y^4 + p y^2 + q y + r = 0: real roots into y[0..3], returns count.  Stands in for the
 // per-ray roots() of MATLAB/RayToX/RayToTorus.m:137-141.
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef RT_INLINE_ALL
+#define RT_COLD __device__ __forceinline__
+#else
 #define RT_COLD __device__ __noinline__ /* out of line: its cbrt/acos temporaries stay out of the surface loop's registers */
+#endif
 #else
 #define RT_COLD static inline
 #endif
@@ -579,10 +644,24 @@ struct Bounce {
 };
 
 // python/RayTracer2.py:275-519 (MATLAB/RayTracer2.m:301-553) for one ray of the live list.
-RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
-    Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
+#if defined(RT_OOL_FIND_HIT) && defined(__HIP_DEVICE_COMPILE__)
+// The kernel keeps the nearest-hit search out of line (defined in rt_kernels.hip): its registers are then allocated
+// on their own instead of competing with the ray state and the physics temporaries of the caller.
+__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last);
+#endif
+RT_HD void bounce_hit(const Geom& G, const Prm& P, RayState& q, Hit& h) {
     q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
-    Hit h; find_hit(G, P, q.p, q.r.d, q.six_last, h);
+#if defined(RT_OOL_FIND_HIT) && defined(__HIP_DEVICE_COMPILE__)
+    h = find_hit_ool(q.p, q.r.d, q.six_last);
+#else
+    find_hit(G, P, q.p, q.r.d, q.six_last, h);
+#endif
+}
+// CF >= 0: the flags are known at compile time (the kernel is instantiated per flag set, so that fields of Bounce that
+// only feed records/final rows are dead code in the tally-only variants); CF < 0: read P.flags.
+template <int CF = -1> RT_HD void bounce_phys(const Geom& G, const Prm& P, RayState& q, const Hit& h, Bounce& b) {
+    const int flags = CF >= 0 ? CF : P.flags;
+    Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
     b.scat = 0; b.surf_sc = 0; b.ray_sc = 0; b.fa = 0; b.fb = 0; b.smix_next = 0; b.six_next = 0; b.surf0 = h.surf; b.orient = h.orient;
     b.l = h.l;
@@ -596,7 +675,7 @@ RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
     double absn = row[17];
     V3 pn = q.p + h.l * q.r.d;
     b.nmech = surface_normal(row, pn, q.r.d, h.orient);
-    V3 sopt = (st == ST_RETRO) ? -q.r.d : b.nmech; // RayTracer2.m:332-333
+    V3 sopt = sel(st == ST_RETRO, -q.r.d, b.nmech); // RayTracer2.m:332-333
     b.smix_next = b.six_next = (h.surf + P.base) * h.orient; // RayTracer2.py:371
     if (st == ST_DIFFUSE) { // RayTracer2.m:394-415
         double ct = sqrt(rng_uniform(g)), stt = sqrt(1 - ct * ct), ph = rng_uniform(g) * TWO_PI, sph, cph;
@@ -627,7 +706,7 @@ RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
     }
     if (b.surf_sc) { double f = 1 - absn; b.refr.s0 *= f; b.refr.s1 *= f; b.refr.s2 *= f; b.refr.s3 *= f; b.refl.s0 *= f; b.refl.s1 *= f; b.refl.s2 *= f; b.refl.s3 *= f; } // :447-449
     if (b.ray_sc) b.refl = rayleigh(g, b.inc, G.lut, G.lut_prec); // :452-454
-    if (P.flags & FLAG_SINGLE) { // :458-467
+    if (flags & FLAG_SINGLE) { // :458-467
         double tot = b.refl.s0 + b.refr.s0;
         bool roll = rng_uniform(g) < (b.refl.s0 / tot);
         if (roll) b.refr = b.refl;
@@ -641,10 +720,14 @@ RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
     b.fa = b.refr.s0 > P.thrA; b.fb = b.refl.s0 > P.thrB; // :518-519
 }
 
+template <int CF = -1> RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
+    Hit h; bounce_hit(G, P, q, h); bounce_phys<CF>(G, P, q, h, b);
+}
+
 // state of a child ray (python/RayTracer2.py:531-540)
 RT_HD RayState child_of(const RayState& q, const Bounce& b, bool reflected, bool primary_goes_to_refr) {
     RayState c;
-    c.p = b.p; c.r = reflected ? b.refl : b.refr;
+    c.p = b.p; c.r = sel(reflected, b.refl, b.refr);
     c.ray_id = q.ray_id; c.parent = -1; c.k = q.k + 1;
     c.hash = path_hash(q.hash, q.k, reflected ? 1 : 0);
     c.smix_last = reflected ? b.smix_next : -b.smix_next;
@@ -681,7 +764,7 @@ RT_HD void fill_final(const RayState& q, const Bounce& b, const Prm& P, double* 
     dst[16] = (double)b.six_next; dst[17] = (double)b.orient; dst[18] = ray_index_of(q, P); dst[19] = (double)(q.k + 1);
     dst[20] = (b.fa ? b.refr.s0 : 0.0) + (b.fb ? b.refl.s0 : 0.0);
     dst[21] = (b.fa || b.fb) ? ((q.k + 1 >= P.K) ? 2.0 : 0.0) : 1.0;
-    const Ray10& o = b.fa ? b.refr : b.refl;
+    const Ray10 o = sel(b.fa != 0, b.refr, b.refl);
     dst[22] = o.d.x; dst[23] = o.d.y; dst[24] = o.d.z; dst[25] = o.pol.x; dst[26] = o.pol.y; dst[27] = o.pol.z;
     dst[28] = o.s1; dst[29] = o.s2; dst[30] = o.s3; dst[31] = 0.0;
 }

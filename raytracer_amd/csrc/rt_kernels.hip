@@ -28,6 +28,9 @@
 #else
 #define RT_ANY(x) (x)
 #endif
+#ifndef RT_INLINE_ALL
+#define RT_OOL_FIND_HIT 1
+#endif
 #include "rt_device.hpp"
 #include "../../include/rt_mi355x.h"
 
@@ -60,8 +63,9 @@ struct KArgs {
     // tallies
     double* table; unsigned long long* n_live; unsigned long long* n_scat;
     int* overflow;
+    unsigned long long* prof; // RT_PROFILE builds: per-phase cycle sums (diagnostic only, never read by the kernel)
     // geometry
-    const double* surf; int S; const double* atoms; int n_atoms; const uint32_t* code; int n_code; const uint32_t* smeta; const uint32_t* ameta; const double* lut; int lut_prec;
+    const double* surf; int S; const double* recs; const uint32_t* smeta; const double* lut; int lut_prec;
     Prm P;
     int rows_lds;           // absorption_table rows kept in LDS (the rest goes straight to global atomics)
     int refill_min;         // refill when at least this many lanes of the wave are idle (or all are)
@@ -93,7 +97,7 @@ __device__ __forceinline__ void gen_point_ray(const KArgs& a, int64_t ray_id, V3
     r.s0 = 1; r.s1 = r.s2 = r.s3 = 0;
 }
 
-__device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& q) {
+__device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& q, bool wantfin) {
     if (a.mode == 1) {
         const double* d = a.in_d; const int64_t st = a.in_stride;
         q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
@@ -113,7 +117,7 @@ __device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& 
         q.r.d = (1.0 / sqrt(dot(dir, dir))) * dir; q.r.pol = (1.0 / sqrt(dot(pol, pol))) * pol; // RayTracer2.py:221-222
         q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
     }
-    if (a.P.flags & FLAG_FINAL) { // row of a ray that never interacts
+    if (wantfin) { // row of a ray that never interacts
         double* f = a.fin + (q.ray_id - a.slot_base) * FIN;
         f[0] = q.p.x; f[1] = q.p.y; f[2] = q.p.z;
         put_ray10(f, 1, 3, q.r);
@@ -144,30 +148,73 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* cou
     return base + (unsigned long long)__popcll(act & ((1ull << lane) - 1ull));
 }
 
+// Block-uniform arguments of the out-of-line nearest-hit search, at the start of dynamic LDS.  A non-kernel function
+// receives its arguments in vector registers, which would turn every geometry read into a per-lane load; read from
+// here and made scalar with readfirstlane they stay in SGPRs and the table reads stay scalar loads.
+struct LdsHdr { unsigned long long surf, recs, smeta; double min_travel; int S, compat, base, pad; };
+constexpr int HDR_DOUBLES = 8;
+static_assert(sizeof(LdsHdr) <= HDR_DOUBLES * 8, "LdsHdr");
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) { return ((unsigned long long)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
+} // namespace
+namespace rt {
+#ifdef RT_OOL_FIND_HIT
+__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last) {
+    extern __shared__ double smem[];
+    const LdsHdr* H = (const LdsHdr*)smem;
+    Geom G; Prm P;
+    G.usurf = (udptr)uni64(H->surf); G.urec = (udptr)uni64(H->recs); G.smeta = (uuptr)uni64(H->smeta);
+    G.surf = nullptr; G.lut = nullptr; G.lut_prec = 0; G.S = (int)uni32((uint32_t)H->S);
+    P.compat = (int)uni32((uint32_t)H->compat); P.base = (int)uni32((uint32_t)H->base);
+    unsigned long long mt = uni64((unsigned long long)__double_as_longlong(H->min_travel));
+    P.min_travel = __longlong_as_double((long long)mt);
+    P.K = 0; P.flags = 0; P.maxiter = 0; P.thrA = P.thrB = P.tir = 0; P.key0 = P.key1 = 0;
+    Hit h; find_hit(G, P, sp, d, six_last, h);
+    return h;
+}
+#endif
+} // namespace rt
+namespace {
 #ifndef RT_WAVES
 #define RT_WAVES 4
 #endif
-__global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
+// CF: flag set this instance is compiled for (FLAG_SINGLE exact; FLAG_FULL/FLAG_FINAL = "may be requested", 0 = never)
+template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
     extern __shared__ double smem[];
     // LDS image: surface rows (per-lane gather of the winning surface) | tally rows | per-step counters
-    double* s_surf = smem;
+    double* s_surf = smem + HDR_DOUBLES;
     double* s_tab = s_surf + a.S * ROW;
     const int ntab = a.rows_lds * 5 * a.S * 2;
     uint32_t* s_live = (uint32_t*)(s_tab + ntab);
     uint32_t* s_scat = s_live + a.P.K;
+    if (threadIdx.x == 0) {
+        LdsHdr* H = (LdsHdr*)smem;
+        H->surf = (unsigned long long)a.surf; H->recs = (unsigned long long)a.recs; H->smeta = (unsigned long long)a.smeta;
+        H->min_travel = a.P.min_travel; H->S = a.S; H->compat = a.P.compat; H->base = a.P.base;
+    }
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
     for (int i = threadIdx.x; i < 2 * a.P.K; i += BLOCK) s_live[i] = 0u;
     __syncthreads();
 
-    Geom G{ (udptr)a.surf, (udptr)a.atoms, (uuptr)a.code, (uuptr)a.smeta, (uuptr)a.ameta, s_surf, a.S, a.lut, a.lut_prec };
+    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec };
     const Prm P = a.P;
     const int lane = lane_id();
     RayState q;
     bool alive = false, more = true;
-    const bool full = (P.flags & FLAG_FULL) != 0, wantfin = (P.flags & FLAG_FINAL) != 0;
+    const bool full = (CF & FLAG_FULL) && (P.flags & FLAG_FULL), wantfin = (CF & FLAG_FINAL) && (P.flags & FLAG_FINAL);
+    constexpr int BF = CF & FLAG_SINGLE; // what the per-ray arithmetic needs to know
 
+#ifdef RT_PROFILE
+    long long pt[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; long long t0, t1;
+#define PROF_T0() t0 = (long long)__builtin_readcyclecounter()
+#define PROF_ADD(i) { t1 = (long long)__builtin_readcyclecounter(); pt[i] += t1 - t0; t0 = t1; }
+#else
+#define PROF_T0()
+#define PROF_ADD(i)
+#endif
     for (;;) {
+        PROF_T0();
         if (more) {
             unsigned long long need = __ballot(!alive);
             int cnt = __popcll(need);
@@ -181,16 +228,29 @@ __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
                 else {
                     if (!alive) {
                         unsigned long long idx = base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
-                        if (idx < (unsigned long long)a.n_in) { load_ray(a, (int64_t)idx, q); alive = true; }
+                        if (idx < (unsigned long long)a.n_in) { load_ray(a, (int64_t)idx, q, wantfin); alive = true; }
                     }
                     if (base + (unsigned long long)cnt >= (unsigned long long)a.n_in) more = false;
                 }
             }
         }
+        PROF_ADD(0)
         if (__ballot(alive) == 0ull) { if (!more) break; continue; }
+#ifdef RT_PROFILE
+        pt[5] += 1; pt[6] += __popcll(__ballot(alive));
+#endif
+#ifdef RT_PROFILE
+        Hit h; h.l = INFINITY; h.surf = -1; h.orient = 0;
+        if (alive) bounce_hit(G, P, q, h);
+        PROF_ADD(1)
+        Bounce b; b.scat = 0;
+        if (alive) bounce_phys<BF>(G, P, q, h, b);
+#else
+        Bounce b; b.scat = 0;
+        if (alive) bounce<BF>(G, P, q, b); // one call: splitting it at the hit/physics seam costs ~9 % (register allocation)
+#endif
+        PROF_ADD(2)
         if (alive) {
-            Bounce b;
-            bounce(G, P, q, b);
             const int k = q.k;
             atomicAdd(&s_live[k], 1u);
             if (!b.scat) { // escaped: RayTracer2.py:485-486
@@ -228,7 +288,11 @@ __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
                 }
             }
         }
+        PROF_ADD(3)
     }
+#ifdef RT_PROFILE
+    if (lane == 0 && a.prof) for (int i = 0; i < 12; i++) atomicAdd(&a.prof[i], (unsigned long long)pt[i]);
+#endif
     __syncthreads();
     for (int i = threadIdx.x; i < ntab; i += BLOCK) { double v = s_tab[i]; if (v != 0.0) atomicAdd(&a.table[i], v); }
     for (int i = threadIdx.x; i < a.P.K; i += BLOCK) {
@@ -266,7 +330,7 @@ struct rt_ctx {
     int device = 0; hipStream_t stream = nullptr; int n_cu = 0; size_t hbm = 0; std::string name;
     std::string err;
     // geometry
-    double* d_surf = nullptr; double* d_atoms = nullptr; uint32_t* d_code = nullptr; uint32_t* d_smeta = nullptr; uint32_t* d_ameta = nullptr; double* d_lut = nullptr;
+    double* d_surf = nullptr; double* d_recs = nullptr; uint32_t* d_smeta = nullptr; double* d_lut = nullptr;
     bool has_rayleigh = false;
     int S = 0, n_atoms = 0, n_code = 0, lut_n = 0;
     // persistent small buffers
@@ -298,7 +362,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { g_init_err = "rt_init: cannot create stream"; delete ctx; return -1; }
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, device);
     ctx->n_cu = pr.multiProcessorCount; ctx->hbm = pr.totalGlobalMem; ctx->name = pr.gcnArchName;
-    if (hipMalloc(&ctx->d_counters, 64) != hipSuccess) { g_init_err = "rt_init: hipMalloc failed"; delete ctx; return -1; }
+    if (hipMalloc(&ctx->d_counters, 256) != hipSuccess) { g_init_err = "rt_init: hipMalloc failed"; delete ctx; return -1; }
     const char* ws = getenv("RT_WORKSPACE_GB"); if (ws && atof(ws) > 0) ctx->workspace_bytes = (size_t)(atof(ws) * (double)(1ull << 30));
     const char* rf = getenv("RT_REFILL_MIN"); if (rf && atoi(rf) > 0) ctx->refill_min = atoi(rf);
     const char* bc = getenv("RT_BLOCKS_PER_CU"); if (bc && atoi(bc) > 0) ctx->blocks_per_cu = atoi(bc);
@@ -309,7 +373,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
 extern "C" void rt_free(rt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); hipFree(ctx->d_smeta); hipFree(ctx->d_ameta); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps);
+    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -358,19 +422,16 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
         if (kind == 3) { int ax = (int)atoms[(size_t)i * ATOM + 3]; if (ax < 0 || ax > 2) { ctx->err = "rt_set_surfaces: bad coordinate atom"; return -1; } }
     }
     CK(hipSetDevice(ctx->device));
-    hipFree(ctx->d_surf); hipFree(ctx->d_atoms); hipFree(ctx->d_code); hipFree(ctx->d_smeta); hipFree(ctx->d_ameta);
-    ctx->d_surf = ctx->d_atoms = nullptr; ctx->d_code = nullptr; ctx->d_smeta = ctx->d_ameta = nullptr;
-    std::vector<double> datoms; std::vector<uint32_t> smeta, ameta;
-    build_device_tables(table, n_surf, atoms, n_atoms, datoms, smeta, ameta);
+    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta);
+    ctx->d_surf = ctx->d_recs = nullptr; ctx->d_smeta = nullptr;
+    std::vector<double> recs; std::vector<uint32_t> smeta;
+    build_device_tables(table, n_surf, atoms, n_atoms, code, recs, smeta);
     CK(hipMalloc(&ctx->d_surf, sizeof(double) * (size_t)n_surf * ROW));
-    CK(hipMalloc(&ctx->d_atoms, sizeof(double) * datoms.size()));
-    CK(hipMalloc(&ctx->d_code, sizeof(uint32_t) * (size_t)(n_code > 0 ? n_code : 1)));
-    CK(hipMalloc(&ctx->d_smeta, 4 * smeta.size())); CK(hipMalloc(&ctx->d_ameta, 4 * ameta.size()));
+    CK(hipMalloc(&ctx->d_recs, sizeof(double) * recs.size()));
+    CK(hipMalloc(&ctx->d_smeta, 4 * smeta.size()));
     CK(hipMemcpy(ctx->d_surf, table, sizeof(double) * (size_t)n_surf * ROW, hipMemcpyHostToDevice));
-    CK(hipMemcpy(ctx->d_atoms, datoms.data(), sizeof(double) * datoms.size(), hipMemcpyHostToDevice));
-    if (n_code) CK(hipMemcpy(ctx->d_code, code, sizeof(uint32_t) * (size_t)n_code, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_recs, recs.data(), sizeof(double) * recs.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(ctx->d_smeta, smeta.data(), 4 * smeta.size(), hipMemcpyHostToDevice));
-    CK(hipMemcpy(ctx->d_ameta, ameta.data(), 4 * ameta.size(), hipMemcpyHostToDevice));
     ctx->has_rayleigh = false;
     for (int s = 0; s < n_surf; s++) if (table[(size_t)s * ROW + 20] < INFINITY || table[(size_t)s * ROW + 21] < INFINITY) ctx->has_rayleigh = true;
     ctx->S = n_surf; ctx->n_atoms = n_atoms; ctx->n_code = n_code;
@@ -421,16 +482,18 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 
     // ---- LDS budget: surface rows + as many absorption_table rows as fit in lds_budget (the first steps carry almost
     // all interactions; deeper rows go to global atomics)
-    const int n_atoms = ctx->n_atoms, n_code = ctx->n_code;
-    size_t fixed = (size_t)S * ROW * 8 + (size_t)2 * K * 4;
+    size_t fixed = (size_t)HDR_DOUBLES * 8 + (size_t)S * ROW * 8 + (size_t)2 * K * 4;
     const size_t lds_max = ctx->lds_budget;
     size_t rowb = (size_t)5 * S * 2 * 8;
     int rows_lds = fixed + rowb <= lds_max ? (int)std::min<size_t>((size_t)K, (lds_max - fixed) / rowb) : 0;
     size_t lds = fixed + (size_t)rows_lds * rowb;
     if (lds > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
-    CK(hipFuncSetAttribute((const void*)k_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // kernel instance: exact on single-child; records/final rows compiled in only when one of them is requested
+    const bool out = full || wantfin;
+    void (*kern)(const KArgs) = single ? (out ? k_trace<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : k_trace<FLAG_SINGLE>) : (out ? k_trace<FLAG_FULL | FLAG_FINAL> : k_trace<0>);
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int bpc = ctx->blocks_per_cu;
-    if (bpc <= 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace, BLOCK, lds) != hipSuccess || nb < 1) nb = 1; bpc = nb > 8 ? 8 : nb; }
+    if (bpc <= 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, lds) != hipSuccess || nb < 1) nb = 1; bpc = nb > 8 ? 8 : nb; }
     // ---- chunking
     const size_t W = ctx->workspace_bytes;
     const size_t rec_bytes = (size_t)REC * 8 + 4 + 8 + 8 + 4;
@@ -458,13 +521,13 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (wantfin) CK(hipMalloc(&b_fin.p, (size_t)FIN * 8 * (size_t)chunk));
 
     KArgs a; memset(&a, 0, sizeof a);
-    a.surf = ctx->d_surf; a.S = S; a.atoms = ctx->d_atoms; a.n_atoms = n_atoms; a.code = ctx->d_code; a.n_code = n_code; a.smeta = ctx->d_smeta; a.ameta = ctx->d_ameta;
+    a.surf = ctx->d_surf; a.S = S; a.recs = ctx->d_recs; a.smeta = ctx->d_smeta;
     a.lut = ctx->d_lut; a.lut_prec = ctx->lut_n > 0 ? ctx->lut_n - 1 : 1;
     a.P.K = K; a.P.flags = prm->flags; a.P.compat = prm->compat; a.P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
     a.P.base = (prm->compat & RT_COMPAT_PY_INDEX) ? 0 : 1; a.P.min_travel = prm->min_travel_length; a.P.thrA = prm->follow_threshold[0]; a.P.thrB = prm->follow_threshold[1];
     a.P.tir = prm->tir_handling; a.P.key0 = (uint32_t)prm->seed; a.P.key1 = (uint32_t)(prm->seed >> 32);
     a.table = ctx->d_table; a.n_live = ctx->d_steps; a.n_scat = ctx->d_steps + K;
-    a.head = ctx->d_counters; a.tail = ctx->d_counters + 1; a.rec_count = ctx->d_counters + 2; a.overflow = (int*)(ctx->d_counters + 3);
+    a.prof = ctx->d_counters + 8; a.head = ctx->d_counters; a.tail = ctx->d_counters + 1; a.rec_count = ctx->d_counters + 2; a.overflow = (int*)(ctx->d_counters + 3);
     a.rec = (double*)b_rec.p; a.rec_cap = rec_cap; a.rec_step = (int32_t*)b_rstep.p; a.rec_ray = (int64_t*)b_rray.p; a.rec_parent = (int64_t*)b_rpar.p; a.rec_flags = (int32_t*)b_rflag.p;
     a.fin = (double*)b_fin.p; a.rows_lds = rows_lds; a.refill_min = ctx->refill_min;
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
@@ -489,7 +552,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             a.out = q[cur];
             int64_t blocks = std::min<int64_t>((a.n_in + BLOCK - 1) / BLOCK, (int64_t)ctx->n_cu * bpc);
             CK(hipEventRecord(ev0, ctx->stream));
-            hipLaunchKernelGGL(k_trace, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, a);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, a);
             CK(hipEventRecord(ev1, ctx->stream));
             CK(hipGetLastError());
             unsigned long long cnt[4];
@@ -566,6 +629,14 @@ extern "C" int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int
     return 0;
 }
 
+// diagnostic builds (-DRT_PROFILE) only, 16 counters: cycle sums {refill, find_hit, physics, tally+output}, solver calls, wave passes,
+// live lanes, lanes wanting a torus solve, candidate-block cycles, candidate blocks
+extern "C" int rt_debug_profile(rt_ctx* ctx, unsigned long long* out8, int reset) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (out8 && hipMemcpy(out8, ctx->d_counters + 8, 128, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset && hipMemset(ctx->d_counters + 8, 0, 128) != hipSuccess) return -1;
+    return 0;
+}
 extern "C" int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps) { *num_steps = ctx->num_steps; return 0; }
 extern "C" int rt_result_table(rt_ctx* ctx, double* table) { memcpy(table, ctx->table.data(), sizeof(double) * (size_t)ctx->num_steps * 5 * ctx->S * 2); return 0; }
 extern "C" int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live, int64_t* n_scat) {

@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/mkvar.sh NAME [git-rev] [extra flags]: build build/rt_NAME.so from the working tree (or from a git revision's csrc)
+set -e
+name=$1; rev=$2; shift; shift || true
+root=$(cd $(dirname $0)/.. && pwd)
+src=$root/raytracer_amd/csrc
+if [ -n "$rev" ] && [ "$rev" != "WT" ]; then
+  tmp=$(mktemp -d); mkdir -p $tmp/raytracer_amd/csrc $tmp/include
+  git -C $root show $rev:raytracer_amd/csrc/rt_kernels.hip > $tmp/raytracer_amd/csrc/rt_kernels.hip
+  git -C $root show $rev:raytracer_amd/csrc/rt_device.hpp > $tmp/raytracer_amd/csrc/rt_device.hpp
+  git -C $root show $rev:include/rt_mi355x.h > $tmp/include/rt_mi355x.h
+  src=$tmp/raytracer_amd/csrc
+fi
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -munsafe-fp-atomics -I$root/include "$@" -o $root/build/rt_$name.so $src/rt_kernels.hip
+echo built build/rt_$name.so
