@@ -70,7 +70,7 @@ typedef const RT_UNIFORM double* udptr;
 typedef const RT_UNIFORM uint32_t* uuptr;
 // smeta: 4 uint32 per surface {shape, surface type, first bounds record, number of bounds records}; urec: the bounds
 // programs in device form, one 64-byte record per step (see build_device_tables()).
-struct Geom { udptr usurf; udptr urec; uuptr smeta; const double* surf; int S; const double* lut; int lut_prec; };
+struct Geom { udptr usurf; udptr urec; uuptr smeta; const double* surf; int S; const double* lut; int lut_prec; double* tq; };
 struct Prm {
     int K, flags, compat, maxiter, base;
     double min_travel, thrA, thrB, tir;
@@ -116,52 +116,54 @@ RT_HD uint32_t path_hash(uint32_t h, int step, int reflected) {
 // called at python/RayTracer2.py:316).  The program is the same for every lane: control flow is wave-uniform.
 //
 // Device form.  The public program (postfix code words that index a separate atom table) costs three dependent
-// scalar loads per atom (code word -> atom -> next code word), and the bounds test sits on the critical path of every
-// candidate hit, so build_device_tables() flattens it into self-contained 64-byte records {meta, rhs, c0..c5}: one
-// scalar load per step, at an address known before the previous step has been looked at (the next record is
-// requested while the current one is evaluated).  meta (low 32 bits of the first double):
-//   bits 0-3 kind, 4-5 comparison (0 <, 1 <=, 2 ==, 3 !=), 6-7 axis, 8 negate, 9 add the accumulator, 10 push the
-//   comparison result, 12-15 number of trailing stack operations, 16-30 those operations (3 bits each).
-// Every ordering atom is stored as '<' or '<=' ('>' and '>=' are negated: -(v) < -(rhs) <=> v > rhs in IEEE
-// arithmetic, NaN included, both false).
-enum { BK_COORD = 0, BK_LIN = 1, BK_QDIAG = 2, BK_ACCX = 3, BK_ACC4 = 4, BK_ATAN2 = 5, BK_CONST = 6, BK_NONE = 7 };
-constexpr int BREC = 8; // doubles per record
+// scalar loads per atom, and the bounds test sits on the critical path of every candidate hit, so
+// build_device_tables() flattens it into self-contained 80-byte records {meta, hi, c0..c5, lo, -}: one scalar load
+// per step at an address known in advance (the first record is requested as soon as the surface is known, each
+// further one while its predecessor is evaluated).  The common atoms (coordinate, linear, axis-aligned quadratic) are
+// one record kind, v = c0 x^2 + c1 y^2 + c2 z^2 + c3 x + c4 y + c5 z, evaluated without a branch, and "lo < v <= hi"
+// written as two atoms and an AND (how every slab, ring and range in the reference's geometries is written) is
+// fused into one record.  meta (low 32 bits of the first double):
+//   bits 0-3 kind; 4 upper bound inclusive; 5 has lower bound; 6 lower bound inclusive; 7 "== hi"; 8 "!= hi";
+//   13 push the result; 16-19 number of trailing stack operations; 20-31 those operations (3 bits each).
+// '>' and '>=' atoms are stored negated: -(v) < -(rhs) <=> v > rhs in IEEE arithmetic, NaN included (both false).
+enum { BK_POLY = 0, BK_ACCX = 3, BK_ACC4 = 4, BK_ATAN2 = 5, BK_CONST = 6, BK_NONE = 7 };
+enum { BM_UPEQ = 16, BM_HASLO = 32, BM_LOEQ = 64, BM_EQ = 128, BM_NE = 256, BM_PUSH = 8192 };
+constexpr int BREC = 10; // doubles per record
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __noinline__ double atan2_atom(double y, double x) { return atan2(y, x); } // rare: keep its registers out of the hot loop
 #else
 static inline double atan2_atom(double y, double x) { return atan2(y, x); }
 #endif
 struct BRec { double w[BREC]; };
-RT_HD BRec brec_load(udptr r) { BRec b; for (int j = 0; j < BREC; j++) b.w[j] = r[j]; return b; } // one 64-byte scalar load
-RT_HD bool inbounds(const Geom& G, int off, int len, V3 p) {
+RT_HD BRec brec_load(udptr r) { BRec b; for (int j = 0; j < BREC; j++) b.w[j] = r[j]; return b; }
+// `first` = record `off`, already loaded (or anything if len == 0)
+RT_HD bool inbounds(const Geom& G, const BRec& first, int off, int len, V3 p) {
     if (len == 0) return true;
     uint32_t st = 0;
     double acc = 0;
     udptr r = G.urec + (size_t)off * BREC;
-    BRec nxt = brec_load(r);
+    BRec nxt = first;
     for (int i = 0; i < len; i++) {
         const BRec c = nxt;
         r += BREC;
         if (i + 1 < len) nxt = brec_load(r); // in flight while this record is evaluated
         uint32_t m; { uint64_t u; memcpy(&u, &c.w[0], 8); m = (uint32_t)u; }
         const uint32_t kind = m & 15u;
-        const double rhs = c.w[1];
+        const double hi = c.w[1], lo = c.w[8];
         double v;
-        if (kind == BK_COORD) { uint32_t ax = (m >> 6) & 3u; v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z); if (m & 256u) v = -v; }
-        else if (kind == BK_LIN) v = c.w[2] * p.x + c.w[3] * p.y + c.w[4] * p.z;
-        else if (kind == BK_QDIAG) v = c.w[2] * p.x * p.x + c.w[3] * p.y * p.y + c.w[4] * p.z * p.z + c.w[5] * p.x + c.w[6] * p.y + c.w[7] * p.z;
+        if (kind == BK_POLY) { v = c.w[2] * p.x * p.x + c.w[3] * p.y * p.y + c.w[4] * p.z * p.z + c.w[5] * p.x + c.w[6] * p.y + c.w[7] * p.z + acc; acc = 0; }
         else if (kind == BK_ACCX) { acc = c.w[2] * p.x * p.y + c.w[3] * p.x * p.z + c.w[4] * p.y * p.z; v = 0; }
         else if (kind == BK_ACC4) { acc = c.w[2] * p.x + c.w[3] * p.y + c.w[4] * p.z + c.w[5]; v = 0; }
         else if (kind == BK_ATAN2) { v = atan2_atom(acc, c.w[2] * p.x + c.w[3] * p.y + c.w[4] * p.z + c.w[5]); acc = 0; }
-        else v = 0; // BK_CONST: 0 < rhs
-        if (m & 512u) { v += acc; acc = 0; }
-        if (m & 1024u) {
-            const uint32_t cmp = (m >> 4) & 3u;
-            uint32_t b = cmp == 0 ? (v < rhs) : cmp == 1 ? (v <= rhs) : cmp == 2 ? (v == rhs) : (v != rhs);
-            st = (st << 1) | b;
+        else v = 0; // BK_CONST: 0 < hi; BK_NONE: nothing pushed
+        if (m & BM_PUSH) {
+            const bool up = (m & BM_UPEQ) ? (v <= hi) : (v < hi), lw = (m & BM_LOEQ) ? (v >= lo) : (v > lo);
+            bool bb = up && ((m & BM_HASLO) ? lw : true);
+            if (m & (BM_EQ | BM_NE)) bb = (m & BM_EQ) ? (v == hi) : (v != hi);
+            st = (st << 1) | (bb ? 1u : 0u);
         }
-        uint32_t ops = m >> 16;
-        for (uint32_t k = (m >> 12) & 15u; k > 0; k--, ops >>= 3) {
+        uint32_t ops = m >> 20;
+        for (uint32_t k = (m >> 16) & 15u; k > 0; k--, ops >>= 3) {
             const uint32_t op = ops & 7u, t0 = st & 1u, t1 = (st >> 1) & 1u;
             if (op == 4) st ^= 1u;
             else st = ((st >> 2) << 1) | (op == 2 ? (t0 & t1) : op == 3 ? (t0 | t1) : (t0 ^ t1));
@@ -183,11 +185,14 @@ namespace rt {
 RT_HOST static inline void build_device_tables(const double* table, int S, const double* atoms, int nA, const uint32_t* code, std::vector<double>& recs, std::vector<uint32_t>& smeta) {
     (void)nA;
     smeta.resize((size_t)(S > 0 ? S : 1) * 4); recs.clear();
-    auto emit = [&](uint32_t meta, double rhs, const double* c, int nc) {
+    auto meta_of = [&](size_t rec) { uint32_t m; memcpy(&m, &recs[rec * BREC], 4); return m; };
+    auto set_meta = [&](size_t rec, uint32_t m) { memcpy(&recs[rec * BREC], &m, 4); };
+    auto emit = [&](uint32_t meta, double hi, const double* c, int nc) {
         size_t at = recs.size(); recs.resize(at + BREC, 0.0);
-        memcpy(&recs[at], &meta, 4); recs[at + 1] = rhs;
+        memcpy(&recs[at], &meta, 4); recs[at + 1] = hi;
         for (int j = 0; j < nc; j++) recs[at + 2 + j] = c[j];
     };
+    const int MAXOPS = 4;
     for (int s = 0; s < S; s++) {
         const double* r = table + (size_t)s * ROW;
         const int off = (int)r[27], len = (int)r[28];
@@ -199,41 +204,59 @@ RT_HOST static inline void build_device_tables(const double* table, int S, const
                 const double* a = atoms + (size_t)arg * ATOM;
                 const int kind = (int)a[0], cmp = (int)a[1];
                 const bool neg = (cmp == 2 || cmp == 3); // > , >=  ->  negated < , <=
-                const double sg = neg ? -1.0 : 1.0, rhs = sg * a[2];
-                const uint32_t dc = neg ? (cmp == 2 ? 0u : 1u) : (cmp == 0 ? 0u : cmp == 1 ? 1u : cmp == 4 ? 2u : 3u);
-                const uint32_t push = 1024u | (dc << 4);
-                if (kind == 3) emit(BK_COORD | push | ((uint32_t)(int)a[3] << 6) | (neg ? 256u : 0u), rhs, nullptr, 0);
-                else if (kind == 1) { double c[3] = { sg * a[9], sg * a[10], sg * a[11] }; emit(BK_LIN | push, rhs, c, 3); }
+                const double sg = neg ? -1.0 : 1.0, hi = sg * a[2];
+                const uint32_t cm = BM_PUSH | ((cmp == 1 || cmp == 3) ? BM_UPEQ : 0u) | (cmp == 4 ? BM_EQ : 0u) | (cmp == 5 ? BM_NE : 0u);
+                if (kind == 3) { double c[6] = { 0, 0, 0, 0, 0, 0 }; c[3 + (int)a[3]] = sg; emit(BK_POLY | cm, hi, c, 6); }
+                else if (kind == 1) { double c[6] = { 0, 0, 0, sg * a[9], sg * a[10], sg * a[11] }; emit(BK_POLY | cm, hi, c, 6); }
                 else if (kind == 0) {
-                    const bool cross = a[6] != 0 || a[7] != 0 || a[8] != 0;
-                    if (cross) { double c[3] = { sg * a[6], sg * a[7], sg * a[8] }; emit(BK_ACCX, 0.0, c, 3); }
+                    if (a[6] != 0 || a[7] != 0 || a[8] != 0) { double c[3] = { sg * a[6], sg * a[7], sg * a[8] }; emit(BK_ACCX, 0.0, c, 3); }
                     double c[6] = { sg * a[3], sg * a[4], sg * a[5], sg * a[9], sg * a[10], sg * a[11] };
-                    emit(BK_QDIAG | push | (cross ? 512u : 0u), rhs, c, 6);
+                    emit(BK_POLY | cm, hi, c, 6);
                 } else { // atan2 is odd in its first argument: -atan2(y,x) = atan2(-y,x)
                     double cy[4] = { sg * a[3], sg * a[4], sg * a[5], sg * a[6] }, cx[4] = { a[7], a[8], a[9], a[10] };
-                    emit(BK_ACC4, 0.0, cy, 4); emit(BK_ATAN2 | push, rhs, cx, 4);
+                    emit(BK_ACC4, 0.0, cy, 4); emit(BK_ATAN2 | cm, hi, cx, 4);
                 }
                 last = (long)(recs.size() / BREC) - 1;
             } else if (op == 5 || op == 6) {
-                emit(BK_CONST | 1024u, op == 5 ? 1.0 : 0.0, nullptr, 0); // pushes (0 < rhs)
+                emit(BK_CONST | BM_PUSH, op == 5 ? 1.0 : 0.0, nullptr, 0); // pushes (0 < hi)
                 last = (long)(recs.size() / BREC) - 1;
             } else if (op == 2 || op == 3 || op == 4 || op == 7) {
-                uint32_t meta = 0;
-                if (last >= 0) memcpy(&meta, &recs[(size_t)last * BREC], 4);
-                if (last < 0 || ((meta >> 12) & 15u) >= 5u) { emit(BK_NONE, 0.0, nullptr, 0); last = (long)(recs.size() / BREC) - 1; meta = BK_NONE; }
-                const uint32_t k = (meta >> 12) & 15u;
-                meta = (meta & ~(15u << 12)) | ((k + 1) << 12) | (op << (16 + 3 * k));
-                memcpy(&recs[(size_t)last * BREC], &meta, 4);
+                // "f < a  AND  -f < b" on the same polynomial f: one record with two bounds
+                const long nrec = (long)(recs.size() / BREC);
+                if (op == 2 && last == nrec - 1 && nrec - (long)first >= 2) {
+                    const size_t r2 = (size_t)nrec - 1, r1 = r2 - 1;
+                    const uint32_t m1 = meta_of(r1), m2 = meta_of(r2), plain = ~(uint32_t)BM_UPEQ;
+                    bool ok = (m1 & plain) == (BK_POLY | BM_PUSH) && (m2 & plain) == (BK_POLY | BM_PUSH);
+                    // r1 must not add an accumulator (an ACCX record right before it)
+                    if (ok && r1 > first && (meta_of(r1 - 1) & 15u) == BK_ACCX) ok = false;
+                    for (int j = 2; ok && j < 8; j++) ok = recs[r1 * BREC + j] == -recs[r2 * BREC + j];
+                    if (ok) {
+                        recs[r1 * BREC + 8] = -recs[r2 * BREC + 1];
+                        set_meta(r1, m1 | BM_HASLO | ((m2 & BM_UPEQ) ? BM_LOEQ : 0u));
+                        recs.resize(r2 * BREC); last = (long)r1;
+                        continue;
+                    }
+                }
+                uint32_t meta = last >= 0 ? meta_of((size_t)last) : 0u;
+                if (last < 0 || ((meta >> 16) & 15u) >= (uint32_t)MAXOPS) { emit(BK_NONE, 0.0, nullptr, 0); last = (long)(recs.size() / BREC) - 1; meta = BK_NONE; }
+                const uint32_t k = (meta >> 16) & 15u;
+                meta = (meta & ~(15u << 16)) | ((k + 1) << 16) | (op << (20 + 3 * k));
+                set_meta((size_t)last, meta);
             }
         }
         smeta[4 * s] = (uint32_t)(int)r[0]; smeta[4 * s + 1] = (uint32_t)(int)r[1];
         smeta[4 * s + 2] = (uint32_t)first; smeta[4 * s + 3] = (uint32_t)(recs.size() / BREC - first);
     }
-    if (recs.empty()) recs.resize(BREC, 0.0);
+    recs.resize(recs.size() + BREC, 0.0); // the record after the last program is read (and ignored) by surfaces without bounds
 }
 
 // ---------------------------------------------------------------------------------------------- nearest hit
-struct Hit { double l; int surf; int orient; };
+struct Hit {
+    double l; int surf; int orient;
+#ifdef RT_PROFILE
+    long long pm, ps, pc, pn, pf, pt_; // diagnostic counters of the nearest-hit search (see tools/phase_profile.py)
+#endif
+};
 
 // depressed quartic y^4 + p y^2 + q y + r = 0: real roots into y[0..3], returns count.  Stands in for the
 // per-ray roots() of MATLAB/RayToX/RayToTorus.m:137-141.
@@ -298,91 +321,203 @@ template <class Ptr> RT_HD V3 torus_normal(Ptr g, V3 p) {
     return (1.0 / g[7]) * (uu * (1 - g[6] / un) + yv);
 }
 
+// Wave primitives of the nearest-hit search.  Host build (tests/hostsim): a "wave" of one lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_BALLOT(x) __ballot(x)
+#define RT_WAVE 64
+RT_HD int rt_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+RT_HD int rt_rank(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); } // set bits below my lane
+// LDS instructions of one wave execute in issue order, so a read sees an earlier write of another lane: only the
+// compiler has to be kept from reordering across this point (a fence would also wait for the caller's global atomics)
+RT_HD void rt_wave_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+#else
+#define RT_BALLOT(x) ((x) ? 1ull : 0ull)
+#define RT_WAVE 1
+RT_HD int rt_lane() { return 0; }
+RT_HD int rt_rank(unsigned long long) { return 0; }
+RT_HD void rt_wave_sync() {}
+#endif
+constexpr int TQ_SLOTS = 64, TQ_TORI = 4; // per-wave torus queue: 64 slots of 4 doubles, at most 4 distinct tori pending
+
+// One candidate root l_ of surface n: validity tests of python/RayTracer2.py:316 and the running minimum over
+// (distance, surface order).  Surfaces are normally visited in list order, where "strict <" reproduces :319-321
+// (per-surface argmin, first index wins ties) followed by :362; deferred (torus) candidates arrive out of order and
+// win a tie only against a surface that comes later in the list, which gives the same winner.
+template <bool DEFERRED> RT_HD void try_root(const Geom& G, V3 sp, V3 d, int n, int shape, udptr g, const BRec& b0, int boff, int blen, double lmin, double l_, double s_, bool act, Hit& h) {
+    bool c_ = act && (l_ > lmin) && ((l_ < h.l) || (DEFERRED && l_ == h.l && n < h.surf));
+    if (shape != SH_TORUS) c_ = c_ && (s_ != 0);
+    if (RT_ANY(c_)) {
+#ifdef RT_PROFILE
+        long long t0_ = (long long)__builtin_readcyclecounter();
+#endif
+        if (c_) {
+            V3 p_ = sp + l_ * d;
+            if (shape == SH_TORUS) { // sign of d . normal; normal = (1/r2)(u (1 - R1/|u|) + y): scaled by |u| r2^2 > 0
+                V3 ax = ld3(g + 3), xx = p_ - ld3(g);
+                double xxa = dot(xx, ax); V3 yv = xxa * ax, uu = xx - yv;
+                double un = sqrt(dot(uu, uu));
+                s_ = dot(d, (un - g[6]) * uu + un * yv) * g[7];
+            }
+            int o_ = -isgn(s_);
+            if (o_ != 0 && inbounds(G, b0, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; }
+        }
+#ifdef RT_PROFILE
+        h.pc += (long long)__builtin_readcyclecounter() - t0_; h.pn += 1;
+#endif
+    }
+}
+
 // Nearest valid hit over all surfaces.  Every shape first produces its candidate roots (NaN = none) and the sign of
-// d.normal there; one common loop then applies the validity tests of python/RayTracer2.py:316 and keeps a running
-// strict-< minimum over (surface order, root order), which reproduces :319-321 (per-surface argmin, first index
-// wins ties) followed by :362 (strict <).  `d` is a unit vector (normalised once per step, RayToShape.py:11-14), so
-// the leading coefficient of the sphere quadratic and of the torus quartic is taken as 1.
-RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, Hit& h) {
+// d.normal there; try_root() then applies the validity tests and keeps the running minimum.  `d` is a unit vector
+// (normalised once per step, RayToShape.py:11-14), so the leading coefficient of the sphere quadratic and of the
+// torus quartic is taken as 1.
+//
+// Torus quartics are not solved where they are met: only a few lanes of a wave pass the prefilter of any one torus,
+// but nearly every wave has some lane that does, so solving in place would run the (expensive) solver once per
+// torus per wave at a few percent lane utilisation.  Instead the lanes that need a solve push their depressed
+// quartic into a per-wave queue (G.tq, LDS); when the queue is full, and after the last surface, lanes 0..n-1 solve
+// the n queued quartics in one call and the owners take their roots back.  `act` = this lane carries a live ray; the
+// whole wave must call find_hit together (idle lanes still serve as solver lanes).
+RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, bool act, Hit& h) {
     h.l = INFINITY; h.surf = -1; h.orient = 0;
     const bool py2 = (P.compat & COMPAT_PY_ROOT2) != 0;
-    for (int n = 0; n < G.S; n++) {
-        udptr row = G.usurf + n * ROW;
-        udptr g = row + 2;
-        uuptr sm = G.smeta + 4 * n;
-        const int shape = (int)sm[0], boff = (int)sm[2], blen = (int)sm[3];
-        const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
-        double l0 = NAN, l1 = NAN, l2 = NAN, l3 = NAN, s0 = 0, s1 = 0; // s = d . (outward normal) up to a positive factor
-        int M = 2;
-        if (shape == SH_PLANE) { // RayToPlane.py:35-45
-            V3 pn = ld3(g + 3);
-            double den = dot(d, pn), num = dot(ld3(g) - sp, pn);
-            l0 = num / den; s0 = den; M = 1;
-        } else if (shape == SH_SPHERE) { // RayToSphere.m:72-87 with a = 1: l = -B +- sqrt(B^2 - C)
-            V3 x = sp - ld3(g);
-            double r = g[3], B = dot(d, x), C = dot(x, x) - r * r, D = B * B - C;
-            if (RT_ANY(D >= 0)) {
-                double sq = sqrt(D); // NaN if D < 0: fails every comparison below
-                l0 = sq - B; l1 = py2 ? -l0 : -B - sq;
-                s0 = (B + l0) * r; s1 = (B + l1) * r;
-            }
-        } else if (shape == SH_CYL) { // RayToCylinder.m:84-122
-            V3 ax = ld3(g + 3), x = sp - ld3(g);
-            double r = g[6], xa = dot(x, ax), da = dot(d, ax);
-            V3 u = xa * ax - x, v = da * ax - d;
-            double a = dot(v, v), hb = dot(u, v), c = dot(u, u) - r * r; // hb = b/2
-            if (a != 0) {
-                double ia = 1.0 / a, sq = sqrt(hb * hb - a * c);
-                l0 = (sq - hb) * ia; l1 = py2 ? -l0 : (-hb - sq) * ia;
-            } else if (hb != 0) { l0 = l1 = -0.5 * c / hb; }
-            s0 = (hb + l0 * a) * r; s1 = (hb + l1 * a) * r;
-        } else if (shape == SH_QUAD) { // RayToQuadsurface.m:83-123
-            udptr Q = g; V3 Pv = ld3(g + 9); double R = g[12];
-            V3 dQ = { d.x * Q[0] + d.y * Q[3] + d.z * Q[6], d.x * Q[1] + d.y * Q[4] + d.z * Q[7], d.x * Q[2] + d.y * Q[5] + d.z * Q[8] };
-            V3 sQ = { sp.x * Q[0] + sp.y * Q[3] + sp.z * Q[6], sp.x * Q[1] + sp.y * Q[4] + sp.z * Q[7], sp.x * Q[2] + sp.y * Q[5] + sp.z * Q[8] };
-            double a = dot(dQ, d), sQd = dot(sQ, d), dP = dot(d, Pv), b = dP + dot(dQ, sp) + sQd, c = R + dot(sp, Pv) + dot(sQ, sp);
-            bool lin = (b != 0) && (fabs(4 * a * c) < (100 * 2.220446049250313e-16) * (b * b));
-            if (lin) { l0 = -c / b; l1 = -b / a; }
-            else if (a != 0) { double ia = 0.5 / a, sq = sqrt(b * b - 4 * a * c); l0 = (sq - b) * ia; l1 = (-b - sq) * ia; }
-            double g0 = 2 * sQd + dP; // d . (2 pQ + P) = g0 + 2 l a
-            s0 = g0 + 2 * l0 * a; s1 = g0 + 2 * l1 * a;
-        } else if (shape == SH_TORUS) { // RayToTorus.m:88-159
-            V3 ax = ld3(g + 3), x = sp - ld3(g);
-            double R1 = g[6], r2 = g[7];
-            double t0 = -dot(x, d);
-            V3 xs = x + t0 * d;
-            double X2 = dot(xs, xs), Rb = fabs(R1) + fabs(r2), w = Rb * Rb - X2;
-            // the torus lies inside the sphere of radius R1+r2 about its centre: nothing to solve for rays that miss
-            // that sphere or whose nearest possible hit lies beyond the best hit so far
-            bool maybe = (w >= 0) && (t0 - sqrt(fmax(w, 0.0)) < h.l);
-            M = 0;
-            if (RT_ANY(maybe)) {
-                double xa = dot(xs, ax), da = dot(d, ax), K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
-                double pp = 2 * K - R4 * (1 - da * da), qq = 2 * R4 * xa * da, rr = K * K - R4 * (X2 - xa * xa);
-                Roots4 y = solve_depressed_quartic(pp, qq, rr);
-                l0 = maybe ? y.y0 + t0 : NAN; l1 = maybe ? y.y1 + t0 : NAN; l2 = maybe ? y.y2 + t0 : NAN; l3 = maybe ? y.y3 + t0 : NAN;
-                M = 4;
-            }
-        }
-#pragma unroll 1
-        for (int m = 0; m < M; m++) {
-            double l_ = m == 0 ? l0 : (m == 1 ? l1 : (m == 2 ? l2 : l3));
-            double s_ = m == 0 ? s0 : s1;
-            bool c_ = (l_ > lmin) && (l_ < h.l);
-            if (shape != SH_TORUS) c_ = c_ && (s_ != 0);
-            if (RT_ANY(c_)) {
-                if (c_) {
-                    V3 p_ = sp + l_ * d;
-                    if (shape == SH_TORUS) { // sign of d . normal; normal = (1/r2)(u (1 - R1/|u|) + y): scaled by |u| r2^2 > 0
-                        V3 ax = ld3(g + 3), xx = p_ - ld3(g);
-                        double xxa = dot(xx, ax); V3 yv = xxa * ax, uu = xx - yv;
-                        double un = sqrt(dot(uu, uu));
-                        s_ = dot(d, (un - g[6]) * uu + un * yv) * g[7];
-                    }
-                    int o_ = -isgn(s_);
-                    if (o_ != 0 && inbounds(G, boff, blen, p_)) { h.l = l_; h.surf = n; h.orient = o_; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    double* tq = G.tq;
+#else
+    double tq_host[4 * TQ_SLOTS]; double* tq = tq_host;
+#endif
+    int npend = 0, ntor = 0;             // wave-uniform: slots used, distinct tori pending
+    unsigned long long torpack = 0;      // wave-uniform: 16-bit surface index of each pending torus
+    uint32_t slotpack = 0;               // per lane: 8-bit (slot + 1) for each pending torus, 0 = none
+    for (int n = 0;; n++) {
+        const bool last = n >= G.S;
+        bool flush = last;
+        if (!last) {
+            udptr row = G.usurf + n * ROW;
+            udptr g = row + 2;
+            uuptr sm = G.smeta + 4 * n;
+            const int shape = (int)sm[0], boff = (int)sm[2], blen = (int)sm[3];
+            const BRec b0 = brec_load(G.urec + (size_t)boff * BREC); // first bounds record: on its way while the roots are found
+            const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
+            double l0 = NAN, l1 = NAN, s0 = 0, s1 = 0; // s = d . (outward normal) up to a positive factor
+            int M = 2;
+            if (shape == SH_PLANE) { // RayToPlane.py:35-45
+                V3 pn = ld3(g + 3);
+                double den = dot(d, pn), num = dot(ld3(g) - sp, pn);
+                l0 = num / den; s0 = den; M = 1;
+            } else if (shape == SH_SPHERE) { // RayToSphere.m:72-87 with a = 1: l = -B +- sqrt(B^2 - C)
+                V3 x = sp - ld3(g);
+                double r = g[3], B = dot(d, x), C = dot(x, x) - r * r, D = B * B - C;
+                if (RT_ANY(D >= 0)) {
+                    double sq = sqrt(D); // NaN if D < 0: fails every comparison below
+                    l0 = sq - B; l1 = py2 ? -l0 : -B - sq;
+                    s0 = (B + l0) * r; s1 = (B + l1) * r;
                 }
+            } else if (shape == SH_CYL) { // RayToCylinder.m:84-122
+                V3 ax = ld3(g + 3), x = sp - ld3(g);
+                double r = g[6], xa = dot(x, ax), da = dot(d, ax);
+                V3 u = xa * ax - x, v = da * ax - d;
+                double a = dot(v, v), hb = dot(u, v), c = dot(u, u) - r * r; // hb = b/2
+                if (a != 0) {
+                    double ia = 1.0 / a, sq = sqrt(hb * hb - a * c);
+                    l0 = (sq - hb) * ia; l1 = py2 ? -l0 : (-hb - sq) * ia;
+                } else if (hb != 0) { l0 = l1 = -0.5 * c / hb; }
+                s0 = (hb + l0 * a) * r; s1 = (hb + l1 * a) * r;
+            } else if (shape == SH_QUAD) { // RayToQuadsurface.m:83-123
+                udptr Q = g; V3 Pv = ld3(g + 9); double R = g[12];
+                V3 dQ = { d.x * Q[0] + d.y * Q[3] + d.z * Q[6], d.x * Q[1] + d.y * Q[4] + d.z * Q[7], d.x * Q[2] + d.y * Q[5] + d.z * Q[8] };
+                V3 sQ = { sp.x * Q[0] + sp.y * Q[3] + sp.z * Q[6], sp.x * Q[1] + sp.y * Q[4] + sp.z * Q[7], sp.x * Q[2] + sp.y * Q[5] + sp.z * Q[8] };
+                double a = dot(dQ, d), sQd = dot(sQ, d), dP = dot(d, Pv), b = dP + dot(dQ, sp) + sQd, c = R + dot(sp, Pv) + dot(sQ, sp);
+                bool lin = (b != 0) && (fabs(4 * a * c) < (100 * 2.220446049250313e-16) * (b * b));
+                if (lin) { l0 = -c / b; l1 = -b / a; }
+                else if (a != 0) { double ia = 0.5 / a, sq = sqrt(b * b - 4 * a * c); l0 = (sq - b) * ia; l1 = (-b - sq) * ia; }
+                double g0 = 2 * sQd + dP; // d . (2 pQ + P) = g0 + 2 l a
+                s0 = g0 + 2 * l0 * a; s1 = g0 + 2 * l1 * a;
+            } else if (shape == SH_TORUS) { // RayToTorus.m:88-159
+                M = 0;
+#ifdef RT_PROFILE
+                long long tt_ = (long long)__builtin_readcyclecounter();
+#endif
+                V3 ax = ld3(g + 3), x = sp - ld3(g);
+                double R1 = g[6], r2 = g[7];
+                // The torus lies inside the slab |axial| <= r2 and between the cylinders of radius R1 -+ r2 about its
+                // axis.  Ray parameter interval inside slab, outer cylinder and (lmin, best hit so far); nothing to
+                // solve when it is empty or when the ray stays inside the inner cylinder throughout it (radius^2 is
+                // convex in t: its maximum over an interval is at an end).  r2 is widened by 1e-9 so that rounding
+                // never drops a real root.
+                double re = fabs(r2) * (1 + 1e-9), Ro = fabs(R1) + re, Ri = fabs(R1) - re;
+                double xa0 = dot(x, ax), da = dot(d, ax), xd = dot(x, d), xx = dot(x, x);
+                double ida = 1.0 / da, ta = (-re - xa0) * ida, tb = (re - xa0) * ida;
+                double lo = fmin(ta, tb), hi = fmax(ta, tb);
+                if (da == 0) { bool in = fabs(xa0) <= re; lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; }
+                double qa = 1 - da * da, qb = xd - xa0 * da, qc = xx - xa0 * xa0; // radius^2(t) = qa t^2 + 2 qb t + qc
+                double disc = qb * qb - qa * (qc - Ro * Ro);
+                if (qa > 0) { double iq = 1.0 / qa, sq = sqrt(disc); lo = fmax(lo, (-qb - sq) * iq); hi = fmin(hi, (sq - qb) * iq); }
+                lo = fmax(lo, lmin); hi = fmin(hi, h.l);
+                bool maybe = act && (disc >= 0) && (lo <= hi);
+                if (Ri > 0) maybe = maybe && !(((qa * lo + 2 * qb) * lo + qc < Ri * Ri) && ((qa * hi + 2 * qb) * hi + qc < Ri * Ri));
+                const unsigned long long mb = RT_BALLOT(maybe);
+#ifdef RT_PROFILE
+                h.pm += __popcll(mb);
+#endif
+                if (mb != 0ull) {
+                    const int cnt = __builtin_popcountll(mb);
+                    if (npend + cnt > TQ_SLOTS || ntor == TQ_TORI) { flush = true; n--; } // no room: solve what is queued, then come back
+                    else {
+                        if (maybe) { // depressed quartic about the point of closest approach to the torus centre
+                            int slot = npend + rt_rank(mb);
+                            double t0 = -xd;
+                            V3 xs = x + t0 * d;
+                            double X2 = dot(xs, xs), xa = dot(xs, ax), K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
+                            double* q = tq + 4 * slot;
+                            q[0] = 2 * K - R4 * (1 - da * da); q[1] = 2 * R4 * xa * da; q[2] = K * K - R4 * (X2 - xa * xa); q[3] = t0;
+                            slotpack |= (uint32_t)(slot + 1) << (8 * ntor);
+                        }
+                        torpack |= (unsigned long long)(unsigned)n << (16 * ntor);
+                        ntor++; npend += cnt;
+                    }
+                }
+#ifdef RT_PROFILE
+                h.pt_ += (long long)__builtin_readcyclecounter() - tt_;
+#endif
             }
+#pragma unroll 1
+            for (int m = 0; m < M; m++) try_root<false>(G, sp, d, n, shape, g, b0, boff, blen, lmin, m == 0 ? l0 : l1, m == 0 ? s0 : s1, act, h);
+        }
+        if (flush) {
+            if (npend > 0) {
+#ifdef RT_PROFILE
+                h.ps += 1;
+                long long tf_ = (long long)__builtin_readcyclecounter();
+#endif
+                rt_wave_sync();
+                for (int j = rt_lane(); j < npend; j += RT_WAVE) { // device: one slot per lane
+                    double* q = tq + 4 * j;
+                    double t0 = q[3];
+                    Roots4 y = solve_depressed_quartic(q[0], q[1], q[2]);
+                    q[0] = y.y0 + t0; q[1] = y.y1 + t0; q[2] = y.y2 + t0; q[3] = y.y3 + t0;
+                }
+                rt_wave_sync();
+#pragma unroll 1
+                for (int k = 0; k < ntor; k++) {
+                    const int nt = (int)((torpack >> (16 * k)) & 0xFFFFull);
+                    const uint32_t my = (slotpack >> (8 * k)) & 0xFFu;
+                    udptr g = G.usurf + nt * ROW + 2;
+                    uuptr sm = G.smeta + 4 * nt;
+                    const int boff = (int)sm[2], blen = (int)sm[3];
+                    const BRec b0 = brec_load(G.urec + (size_t)boff * BREC);
+                    const double lmin = (six_last == nt + P.base) ? P.min_travel : 0.0;
+                    const double* q = tq + 4 * (my ? my - 1 : 0);
+#pragma unroll 1
+                    for (int m = 0; m < 4; m++) try_root<true>(G, sp, d, nt, SH_TORUS, g, b0, boff, blen, lmin, my ? q[m] : NAN, 0.0, act, h);
+                }
+                rt_wave_sync();
+#ifdef RT_PROFILE
+                h.pf += (long long)__builtin_readcyclecounter() - tf_;
+#endif
+                npend = 0; ntor = 0; torpack = 0; slotpack = 0;
+            }
+            if (last) break;
         }
     }
 }
@@ -647,14 +782,15 @@ struct Bounce {
 #if defined(RT_OOL_FIND_HIT) && defined(__HIP_DEVICE_COMPILE__)
 // The kernel keeps the nearest-hit search out of line (defined in rt_kernels.hip): its registers are then allocated
 // on their own instead of competing with the ray state and the physics temporaries of the caller.
-__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last);
+__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last, bool act);
 #endif
-RT_HD void bounce_hit(const Geom& G, const Prm& P, RayState& q, Hit& h) {
+// The whole wave calls this together (see find_hit); `act` = this lane carries a live ray.
+RT_HD void bounce_hit(const Geom& G, const Prm& P, RayState& q, bool act, Hit& h) {
     q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
 #if defined(RT_OOL_FIND_HIT) && defined(__HIP_DEVICE_COMPILE__)
-    h = find_hit_ool(q.p, q.r.d, q.six_last);
+    h = find_hit_ool(q.p, q.r.d, q.six_last, act);
 #else
-    find_hit(G, P, q.p, q.r.d, q.six_last, h);
+    find_hit(G, P, q.p, q.r.d, q.six_last, act, h);
 #endif
 }
 // CF >= 0: the flags are known at compile time (the kernel is instantiated per flag set, so that fields of Bounce that
@@ -721,7 +857,7 @@ template <int CF = -1> RT_HD void bounce_phys(const Geom& G, const Prm& P, RaySt
 }
 
 template <int CF = -1> RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
-    Hit h; bounce_hit(G, P, q, h); bounce_phys<CF>(G, P, q, h, b);
+    Hit h; bounce_hit(G, P, q, true, h); bounce_phys<CF>(G, P, q, h, b);
 }
 
 // state of a child ray (python/RayTracer2.py:531-540)

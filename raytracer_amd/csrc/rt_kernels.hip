@@ -153,23 +153,29 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* cou
 // here and made scalar with readfirstlane they stay in SGPRs and the table reads stay scalar loads.
 struct LdsHdr { unsigned long long surf, recs, smeta; double min_travel; int S, compat, base, pad; };
 constexpr int HDR_DOUBLES = 8;
+constexpr int TQ_DOUBLES = (BLOCK / 64) * TQ_SLOTS * 4; // per-wave torus queues, right behind the header
 static_assert(sizeof(LdsHdr) <= HDR_DOUBLES * 8, "LdsHdr");
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) { return ((unsigned long long)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
 } // namespace
 namespace rt {
 #ifdef RT_OOL_FIND_HIT
-__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last) {
+__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last, bool act) {
     extern __shared__ double smem[];
     const LdsHdr* H = (const LdsHdr*)smem;
     Geom G; Prm P;
     G.usurf = (udptr)uni64(H->surf); G.urec = (udptr)uni64(H->recs); G.smeta = (uuptr)uni64(H->smeta);
     G.surf = nullptr; G.lut = nullptr; G.lut_prec = 0; G.S = (int)uni32((uint32_t)H->S);
+    G.tq = smem + HDR_DOUBLES + (int)uni32(threadIdx.x / 64u) * (TQ_SLOTS * 4);
     P.compat = (int)uni32((uint32_t)H->compat); P.base = (int)uni32((uint32_t)H->base);
     unsigned long long mt = uni64((unsigned long long)__double_as_longlong(H->min_travel));
     P.min_travel = __longlong_as_double((long long)mt);
     P.K = 0; P.flags = 0; P.maxiter = 0; P.thrA = P.thrB = P.tir = 0; P.key0 = P.key1 = 0;
-    Hit h; find_hit(G, P, sp, d, six_last, h);
+    Hit h;
+#ifdef RT_PROFILE
+    h.pm = h.ps = h.pc = h.pn = h.pf = h.pt_ = 0;
+#endif
+    find_hit(G, P, sp, d, six_last, act, h);
     return h;
 }
 #endif
@@ -182,7 +188,7 @@ namespace {
 template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
     extern __shared__ double smem[];
     // LDS image: surface rows (per-lane gather of the winning surface) | tally rows | per-step counters
-    double* s_surf = smem + HDR_DOUBLES;
+    double* s_surf = smem + HDR_DOUBLES + TQ_DOUBLES;
     double* s_tab = s_surf + a.S * ROW;
     const int ntab = a.rows_lds * 5 * a.S * 2;
     uint32_t* s_live = (uint32_t*)(s_tab + ntab);
@@ -197,7 +203,7 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(con
     for (int i = threadIdx.x; i < 2 * a.P.K; i += BLOCK) s_live[i] = 0u;
     __syncthreads();
 
-    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec };
+    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, smem + HDR_DOUBLES + (threadIdx.x / 64) * (TQ_SLOTS * 4) };
     const Prm P = a.P;
     const int lane = lane_id();
     RayState q;
@@ -239,16 +245,14 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(con
 #ifdef RT_PROFILE
         pt[5] += 1; pt[6] += __popcll(__ballot(alive));
 #endif
-#ifdef RT_PROFILE
         Hit h; h.l = INFINITY; h.surf = -1; h.orient = 0;
-        if (alive) bounce_hit(G, P, q, h);
+        bounce_hit(G, P, q, alive, h); // all lanes: idle ones still serve the wave's torus queue
+#ifdef RT_PROFILE
+        pt[4] += h.ps; pt[7] += h.pm; pt[8] += h.pc; pt[9] += h.pn; pt[10] += h.pf; pt[11] += h.pt_;
+#endif
         PROF_ADD(1)
         Bounce b; b.scat = 0;
         if (alive) bounce_phys<BF>(G, P, q, h, b);
-#else
-        Bounce b; b.scat = 0;
-        if (alive) bounce<BF>(G, P, q, b); // one call: splitting it at the hit/physics seam costs ~9 % (register allocation)
-#endif
         PROF_ADD(2)
         if (alive) {
             const int k = q.k;
@@ -482,7 +486,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 
     // ---- LDS budget: surface rows + as many absorption_table rows as fit in lds_budget (the first steps carry almost
     // all interactions; deeper rows go to global atomics)
-    size_t fixed = (size_t)HDR_DOUBLES * 8 + (size_t)S * ROW * 8 + (size_t)2 * K * 4;
+    size_t fixed = (size_t)(HDR_DOUBLES + TQ_DOUBLES) * 8 + (size_t)S * ROW * 8 + (size_t)2 * K * 4;
     const size_t lds_max = ctx->lds_budget;
     size_t rowb = (size_t)5 * S * 2 * 8;
     int rows_lds = fixed + rowb <= lds_max ? (int)std::min<size_t>((size_t)K, (lds_max - fixed) / rowb) : 0;

@@ -25,7 +25,7 @@ extern "C" int hs_trace(const double* sp, const double* rays, int64_t n, const d
     for (int si = 0; si < S; si++) { int off = (int)table[(size_t)si * ROW + 27], len = (int)table[(size_t)si * ROW + 28]; for (int i = off; i < off + len; i++) if ((code[i] >> 24) == 1) nA = std::max(nA, (int)(code[i] & 0xFFFFFFu) + 1); }
     std::vector<double> recs; std::vector<uint32_t> smeta;
     build_device_tables(table, S, atoms, nA, code, recs, smeta);
-    Geom G{ table, recs.data(), smeta.data(), table, S, lut, lut_n - 1 };
+    Geom G{ table, recs.data(), smeta.data(), table, S, lut, lut_n - 1, nullptr };
     Prm P; P.K = prm->max_scatters; P.flags = prm->flags; P.compat = prm->compat; P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
     P.base = (prm->compat & COMPAT_PY_INDEX) ? 0 : 1; P.min_travel = prm->min_travel_length; P.thrA = prm->follow_threshold[0]; P.thrB = prm->follow_threshold[1];
     P.tir = prm->tir_handling; P.key0 = (uint32_t)prm->seed; P.key1 = (uint32_t)(prm->seed >> 32);
