@@ -69,6 +69,10 @@ struct KArgs {
     Prm P;
     int rows_lds;           // absorption_table rows kept in LDS (the rest goes straight to global atomics)
     int refill_min;         // refill when at least this many lanes of the wave are idle (or all are)
+    // level-synchronous path (k_level_hit / k_level_phys)
+    int step;                               // the step k both kernels work on
+    const unsigned long long* cnt_in;       // number of live rays of this step (null: n_in)
+    double* hit_l; int32_t* hit_so;         // nearest hit of live ray i: distance, surface * 4 + orientation + 1 (-1: none)
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -306,6 +310,123 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(con
 }
 
 // host layout (start[n][3], rays[n][10]) -> SoA [13][n]
+
+// ------------------------------------------------------------------------------------------------ level-synchronous path
+// Single-child runs (every ray has at most one child per step) are traced step by step, like the reference's own
+// loop (python/RayTracer2.py:275): the live rays of step k sit in a queue in HBM, k_level_hit finds their nearest hits
+// and k_level_phys applies the physics and writes the surviving children, compacted, into the queue of step k+1.
+// The two halves want different things from the machine: the nearest-hit search is a long chain of uniform (scalar)
+// loads with little per-lane state, so it runs at high occupancy to hide their latency; the physics needs ~130 FP64
+// registers' worth of state and few waves.  Fused into one persistent kernel both ran at 4 waves/SIMD and the physics
+// spilled ~1.2 kB per interaction through scratch to HBM - more than the ~0.4 kB per interaction the queues cost here.
+// Both kernels are grid-stride over the live count, which they read from device memory (no host round trip per step).
+#ifndef RT_HIT_WAVES
+#define RT_HIT_WAVES 5
+#endif
+#ifndef RT_PHYS_WAVES
+#define RT_PHYS_WAVES 4
+#endif
+__device__ __forceinline__ void load_pd(const KArgs& a, int64_t idx, V3& p, V3& d, int& six_last) {
+    if (a.mode == 1) {
+        const double* q = a.in_d; const int64_t st = a.in_stride;
+        p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
+        d = V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] };
+        six_last = a.in_m[3 * st + idx];
+        return;
+    }
+    six_last = 0;
+    if (a.mode == 2) { Ray10 r; gen_point_ray(a, a.ray_id_base + idx, p, r); d = r.d; }
+    else {
+        const double* q = a.in_d; const int64_t st = a.in_stride;
+        p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
+        V3 dir = V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] };
+        d = (1.0 / sqrt(dot(dir, dir))) * dir; // RayTracer2.py:221
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK, RT_HIT_WAVES) k_level_hit(const KArgs a) {
+    extern __shared__ double smem[]; // per-wave torus queues
+    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, nullptr, a.S, nullptr, 0, smem + (threadIdx.x / 64) * (TQ_SLOTS * 4) };
+    const Prm P = a.P;
+    const int64_t n = a.cnt_in ? (int64_t)*a.cnt_in : a.n_in;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t base = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); base < n; base += stride) { // wave-uniform trip count
+        const int64_t idx = base + lane_id();
+        const bool act = idx < n;
+        V3 p = { 0, 0, 0 }, d = { 0, 0, 1 }; int six = 0;
+        if (act) { load_pd(a, idx, p, d, six); d = normalized_if(d); } // RayToShape.py:11-14
+        Hit h; find_hit(G, P, p, d, six, act, h);
+        if (act) { a.hit_l[idx] = h.l; a.hit_so[idx] = h.surf < 0 ? -1 : h.surf * 4 + h.orient + 1; }
+    }
+}
+
+template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_level_phys(const KArgs a) {
+    extern __shared__ double smem[];
+    // LDS image: surface rows (per-lane gather of the winning surface) | this step's tally row | step counters
+    double* s_surf = smem;
+    double* s_tab = s_surf + a.S * ROW;
+    const int ntab = 5 * a.S * 2;
+    uint32_t* s_cnt = (uint32_t*)(s_tab + ntab);
+    for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
+    for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr };
+    const Prm P = a.P;
+    const bool full = (CF & FLAG_FULL) && (P.flags & FLAG_FULL), wantfin = (CF & FLAG_FINAL) && (P.flags & FLAG_FINAL);
+    constexpr int BF = CF & FLAG_SINGLE;
+    const int k = a.step;
+    KArgs t = a; t.rows_lds = 1; // tally_add(): row 0 of the LDS image is step k
+    const int64_t n = a.cnt_in ? (int64_t)*a.cnt_in : a.n_in;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t base = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); base < n; base += stride) {
+        const int64_t idx = base + lane_id();
+        if (idx < n) {
+            RayState q; load_ray(a, idx, q, wantfin);
+            q.k = k;
+            q.r.d = normalized_if(q.r.d);
+            Hit h; h.l = a.hit_l[idx];
+            const int so = a.hit_so[idx];
+            h.surf = so < 0 ? -1 : (so >> 2); h.orient = so < 0 ? 0 : (so & 3) - 1;
+            Bounce b; b.scat = 0;
+            bounce_phys<BF>(G, P, q, h, b);
+            atomicAdd(&s_cnt[0], 1u);
+            if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
+            else {
+                atomicAdd(&s_cnt[1], 1u);
+                if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);
+                tally_add(t, s_tab, 0, 1, b.smix_next, b.bulk_abs);
+                tally_add(t, s_tab, 0, 3, b.smix_next, (b.fa ? 0.0 : b.refr.s0) + (b.fb ? 0.0 : b.refl.s0));
+                tally_add(t, s_tab, 0, 4, b.smix_next, (b.fa ? b.refr.s0 : 0.0) + (b.fb ? b.refl.s0 : 0.0));
+                int64_t myslot = -1;
+                if (full) {
+                    unsigned long long slot = wave_alloc(a.rec_count);
+                    if (slot < (unsigned long long)a.rec_cap) {
+                        fill_record(q, b, P, a.rec + slot, (size_t)a.rec_cap);
+                        a.rec_step[slot] = k; a.rec_ray[slot] = q.ray_id; a.rec_parent[slot] = q.parent; a.rec_flags[slot] = q.flags;
+                        myslot = (int64_t)slot;
+                    } else *a.overflow = 1;
+                }
+                if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + (q.ray_id - a.slot_base) * FIN);
+                if (k + 1 < P.K && (b.fa || b.fb)) { // single child: exactly one of fa, fb can be set
+                    RayState c = child_of(q, b, !b.fa, b.fa != 0);
+                    c.parent = myslot;
+                    unsigned long long slot = wave_alloc(a.tail);
+                    if (slot < (unsigned long long)a.out.cap) store_ray(a.out, (int64_t)slot, c);
+                    else *a.overflow = 2;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* row = a.table + (size_t)k * ntab;
+    for (int i = threadIdx.x; i < ntab; i += BLOCK) { double v = s_tab[i]; if (v != 0.0) atomicAdd(&row[i], v); }
+    if (threadIdx.x == 0) {
+        if (s_cnt[0]) atomicAdd(&a.n_live[k], (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&a.n_scat[k], (unsigned long long)s_cnt[1]);
+    }
+}
+
 __global__ void k_aos_to_soa(const double* start, const double* rays, int64_t n, double* soa) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
