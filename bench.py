@@ -107,11 +107,16 @@ def main():
     org = (C.c_double * 3)(*origin)
     flags = _lib.FLAG_SINGLECHILD
 
+    by_kernel = [[0.0, 0], [0.0, 0], [0.0, 0]]  # k_trace, k_level_hit, k_level_phys: ms, launches
+
     def step(i):
         prm = ctx.params(kw["K"], flags, 0, kw["min_travel"], kw["thr"], kw["tir"], a.seed, (rank * (a.steps + a.warmup) + i) * a.rays)
         ctx._check(ctx.L.rt_trace_point_source(ctx.h, org, a.rays, C.byref(prm)))
         live, scat = ctx.step_counts(kw["K"])
         ms = C.c_double(); nl = C.c_int32(); ctx.L.rt_result_timing(ctx.h, C.byref(ms), C.byref(nl))
+        bk = (C.c_double * 3)(); bn = (C.c_int32 * 3)(); ctx.L.rt_result_timing_by_kernel(ctx.h, bk, bn)
+        for j in range(3):
+            by_kernel[j][0] += bk[j]; by_kernel[j][1] += bn[j]
         return int(scat.sum()), ms.value
 
     def barrier():
@@ -121,6 +126,7 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+    by_kernel[:] = [[0.0, 0], [0.0, 0], [0.0, 0]]
     barrier()
     t0 = time.perf_counter()
     inter = 0; kms = 0.0
@@ -150,6 +156,8 @@ def main():
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                          "traffic": None, "flop_per_interaction": fpi, "kernel": "k_trace", "kernel_ms_per_step": kms / a.steps,
+                         "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
+                                       for j, n in enumerate(("k_trace", "k_level_hit", "k_level_phys"))},
                          "note": "FP64 vector path (no dense contraction, MFMA unused); hbm bytes/interaction is ~0 in the persistent kernel"},
         }
         if not a.no_cpu_baseline and world == 1:

@@ -162,6 +162,8 @@ int rt_result_records(rt_ctx* ctx, double* rec /*[n][RT_REC_COLS]*/, int32_t* st
 int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);
 /* kernel time of the last trace measured with HIP events on the context's stream, and launch count */
 int rt_result_timing(rt_ctx* ctx, double* kernel_ms, int32_t* n_launches);
+/* the same split by kernel: [0] k_trace (persistent bounce kernel), [1] k_level_hit, [2] k_level_phys */
+int rt_result_timing_by_kernel(rt_ctx* ctx, double ms[3], int32_t launches[3]);
 
 /* device properties the host side needs (CU count etc.) */
 int rt_device_info(rt_ctx* ctx, int32_t* n_cu, int64_t* hbm_bytes, char* name, int32_t name_len);

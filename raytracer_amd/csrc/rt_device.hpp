@@ -70,7 +70,8 @@ typedef const RT_UNIFORM double* udptr;
 typedef const RT_UNIFORM uint32_t* uuptr;
 // smeta: 4 uint32 per surface {shape, surface type, first bounds record, number of bounds records}; urec: the bounds
 // programs in device form, one 64-byte record per step (see build_device_tables()).
-struct Geom { udptr usurf; udptr urec; uuptr smeta; const double* surf; int S; const double* lut; int lut_prec; double* tq; };
+// uprog/nprog: the frame program (see find_hit)
+struct Geom { udptr usurf; udptr urec; uuptr smeta; const double* surf; int S; const double* lut; int lut_prec; double* tq; udptr uprog; int nprog; };
 struct Prm {
     int K, flags, compat, maxiter, base;
     double min_travel, thrA, thrB, tir;
@@ -182,9 +183,8 @@ namespace rt {
 #endif
 // Host: public tables of include/rt_mi355x.h -> device form: smeta (integer metadata as integers) and the bounds
 // records described above.
-RT_HOST static inline void build_device_tables(const double* table, int S, const double* atoms, int nA, const uint32_t* code, std::vector<double>& recs, std::vector<uint32_t>& smeta) {
-    (void)nA;
-    smeta.resize((size_t)(S > 0 ? S : 1) * 4); recs.clear();
+// one bounds program (public postfix code) -> device records appended to recs; returns the first record's index
+RT_HOST static inline size_t emit_bounds_program(const uint32_t* code, int len, const double* atoms, std::vector<double>& recs) {
     auto meta_of = [&](size_t rec) { uint32_t m; memcpy(&m, &recs[rec * BREC], 4); return m; };
     auto set_meta = [&](size_t rec, uint32_t m) { memcpy(&recs[rec * BREC], &m, 4); };
     auto emit = [&](uint32_t meta, double hi, const double* c, int nc) {
@@ -193,60 +193,72 @@ RT_HOST static inline void build_device_tables(const double* table, int S, const
         for (int j = 0; j < nc; j++) recs[at + 2 + j] = c[j];
     };
     const int MAXOPS = 4;
+    const size_t first = recs.size() / BREC;
+    long last = -1; // record that can still take trailing stack operations
+    for (int i = 0; i < len; i++) {
+        const uint32_t ins = code[i], op = ins >> 24, arg = ins & 0xFFFFFFu;
+        if (op == 1) {
+            const double* a = atoms + (size_t)arg * ATOM;
+            const int kind = (int)a[0], cmp = (int)a[1];
+            const bool neg = (cmp == 2 || cmp == 3); // > , >=  ->  negated < , <=
+            const double sg = neg ? -1.0 : 1.0, hi = sg * a[2];
+            const uint32_t cm = BM_PUSH | ((cmp == 1 || cmp == 3) ? BM_UPEQ : 0u) | (cmp == 4 ? BM_EQ : 0u) | (cmp == 5 ? BM_NE : 0u);
+            if (kind == 3) { double c[6] = { 0, 0, 0, 0, 0, 0 }; c[3 + (int)a[3]] = sg; emit(BK_POLY | cm, hi, c, 6); }
+            else if (kind == 1) { double c[6] = { 0, 0, 0, sg * a[9], sg * a[10], sg * a[11] }; emit(BK_POLY | cm, hi, c, 6); }
+            else if (kind == 0) {
+                if (a[6] != 0 || a[7] != 0 || a[8] != 0) { double c[3] = { sg * a[6], sg * a[7], sg * a[8] }; emit(BK_ACCX, 0.0, c, 3); }
+                double c[6] = { sg * a[3], sg * a[4], sg * a[5], sg * a[9], sg * a[10], sg * a[11] };
+                emit(BK_POLY | cm, hi, c, 6);
+            } else { // atan2 is odd in its first argument: -atan2(y,x) = atan2(-y,x)
+                double cy[4] = { sg * a[3], sg * a[4], sg * a[5], sg * a[6] }, cx[4] = { a[7], a[8], a[9], a[10] };
+                emit(BK_ACC4, 0.0, cy, 4); emit(BK_ATAN2 | cm, hi, cx, 4);
+            }
+            last = (long)(recs.size() / BREC) - 1;
+        } else if (op == 5 || op == 6) {
+            emit(BK_CONST | BM_PUSH, op == 5 ? 1.0 : 0.0, nullptr, 0); // pushes (0 < hi)
+            last = (long)(recs.size() / BREC) - 1;
+        } else if (op == 2 || op == 3 || op == 4 || op == 7) {
+            // "f < a  AND  -f < b" on the same polynomial f: one record with two bounds
+            const long nrec = (long)(recs.size() / BREC);
+            if (op == 2 && last == nrec - 1 && nrec - (long)first >= 2) {
+                const size_t r2 = (size_t)nrec - 1, r1 = r2 - 1;
+                const uint32_t m1 = meta_of(r1), m2 = meta_of(r2), plain = ~(uint32_t)BM_UPEQ;
+                bool ok = (m1 & plain) == (BK_POLY | BM_PUSH) && (m2 & plain) == (BK_POLY | BM_PUSH);
+                // r1 must not add an accumulator (an ACCX record right before it)
+                if (ok && r1 > first && (meta_of(r1 - 1) & 15u) == BK_ACCX) ok = false;
+                for (int j = 2; ok && j < 8; j++) ok = recs[r1 * BREC + j] == -recs[r2 * BREC + j];
+                if (ok) {
+                    recs[r1 * BREC + 8] = -recs[r2 * BREC + 1];
+                    set_meta(r1, m1 | BM_HASLO | ((m2 & BM_UPEQ) ? BM_LOEQ : 0u));
+                    recs.resize(r2 * BREC); last = (long)r1;
+                    continue;
+                }
+            }
+            uint32_t meta = last >= 0 ? meta_of((size_t)last) : 0u;
+            if (last < 0 || ((meta >> 16) & 15u) >= (uint32_t)MAXOPS) { emit(BK_NONE, 0.0, nullptr, 0); last = (long)(recs.size() / BREC) - 1; meta = BK_NONE; }
+            const uint32_t k = (meta >> 16) & 15u;
+            meta = (meta & ~(15u << 16)) | ((k + 1) << 16) | (op << (20 + 3 * k));
+            set_meta((size_t)last, meta);
+        }
+    }
+    return first;
+}
+
+// Host: public tables of include/rt_mi355x.h -> device form: smeta (integer metadata as integers) and the bounds
+// records described above.  Call build_program() afterwards (it appends residual programs to recs), then
+// finish_device_tables().
+RT_HOST static inline void build_device_tables(const double* table, int S, const double* atoms, int nA, const uint32_t* code, std::vector<double>& recs, std::vector<uint32_t>& smeta) {
+    (void)nA;
+    smeta.resize((size_t)(S > 0 ? S : 1) * 4); recs.clear();
     for (int s = 0; s < S; s++) {
         const double* r = table + (size_t)s * ROW;
         const int off = (int)r[27], len = (int)r[28];
-        const size_t first = recs.size() / BREC;
-        long last = -1; // record that can still take trailing stack operations
-        for (int i = 0; i < len; i++) {
-            const uint32_t ins = code[off + i], op = ins >> 24, arg = ins & 0xFFFFFFu;
-            if (op == 1) {
-                const double* a = atoms + (size_t)arg * ATOM;
-                const int kind = (int)a[0], cmp = (int)a[1];
-                const bool neg = (cmp == 2 || cmp == 3); // > , >=  ->  negated < , <=
-                const double sg = neg ? -1.0 : 1.0, hi = sg * a[2];
-                const uint32_t cm = BM_PUSH | ((cmp == 1 || cmp == 3) ? BM_UPEQ : 0u) | (cmp == 4 ? BM_EQ : 0u) | (cmp == 5 ? BM_NE : 0u);
-                if (kind == 3) { double c[6] = { 0, 0, 0, 0, 0, 0 }; c[3 + (int)a[3]] = sg; emit(BK_POLY | cm, hi, c, 6); }
-                else if (kind == 1) { double c[6] = { 0, 0, 0, sg * a[9], sg * a[10], sg * a[11] }; emit(BK_POLY | cm, hi, c, 6); }
-                else if (kind == 0) {
-                    if (a[6] != 0 || a[7] != 0 || a[8] != 0) { double c[3] = { sg * a[6], sg * a[7], sg * a[8] }; emit(BK_ACCX, 0.0, c, 3); }
-                    double c[6] = { sg * a[3], sg * a[4], sg * a[5], sg * a[9], sg * a[10], sg * a[11] };
-                    emit(BK_POLY | cm, hi, c, 6);
-                } else { // atan2 is odd in its first argument: -atan2(y,x) = atan2(-y,x)
-                    double cy[4] = { sg * a[3], sg * a[4], sg * a[5], sg * a[6] }, cx[4] = { a[7], a[8], a[9], a[10] };
-                    emit(BK_ACC4, 0.0, cy, 4); emit(BK_ATAN2 | cm, hi, cx, 4);
-                }
-                last = (long)(recs.size() / BREC) - 1;
-            } else if (op == 5 || op == 6) {
-                emit(BK_CONST | BM_PUSH, op == 5 ? 1.0 : 0.0, nullptr, 0); // pushes (0 < hi)
-                last = (long)(recs.size() / BREC) - 1;
-            } else if (op == 2 || op == 3 || op == 4 || op == 7) {
-                // "f < a  AND  -f < b" on the same polynomial f: one record with two bounds
-                const long nrec = (long)(recs.size() / BREC);
-                if (op == 2 && last == nrec - 1 && nrec - (long)first >= 2) {
-                    const size_t r2 = (size_t)nrec - 1, r1 = r2 - 1;
-                    const uint32_t m1 = meta_of(r1), m2 = meta_of(r2), plain = ~(uint32_t)BM_UPEQ;
-                    bool ok = (m1 & plain) == (BK_POLY | BM_PUSH) && (m2 & plain) == (BK_POLY | BM_PUSH);
-                    // r1 must not add an accumulator (an ACCX record right before it)
-                    if (ok && r1 > first && (meta_of(r1 - 1) & 15u) == BK_ACCX) ok = false;
-                    for (int j = 2; ok && j < 8; j++) ok = recs[r1 * BREC + j] == -recs[r2 * BREC + j];
-                    if (ok) {
-                        recs[r1 * BREC + 8] = -recs[r2 * BREC + 1];
-                        set_meta(r1, m1 | BM_HASLO | ((m2 & BM_UPEQ) ? BM_LOEQ : 0u));
-                        recs.resize(r2 * BREC); last = (long)r1;
-                        continue;
-                    }
-                }
-                uint32_t meta = last >= 0 ? meta_of((size_t)last) : 0u;
-                if (last < 0 || ((meta >> 16) & 15u) >= (uint32_t)MAXOPS) { emit(BK_NONE, 0.0, nullptr, 0); last = (long)(recs.size() / BREC) - 1; meta = BK_NONE; }
-                const uint32_t k = (meta >> 16) & 15u;
-                meta = (meta & ~(15u << 16)) | ((k + 1) << 16) | (op << (20 + 3 * k));
-                set_meta((size_t)last, meta);
-            }
-        }
+        const size_t first = emit_bounds_program(code + off, len, atoms, recs);
         smeta[4 * s] = (uint32_t)(int)r[0]; smeta[4 * s + 1] = (uint32_t)(int)r[1];
         smeta[4 * s + 2] = (uint32_t)first; smeta[4 * s + 3] = (uint32_t)(recs.size() / BREC - first);
     }
+}
+RT_HOST static inline void finish_device_tables(std::vector<double>& recs) {
     recs.resize(recs.size() + BREC, 0.0); // the record after the last program is read (and ignored) by surfaces without bounds
 }
 
@@ -330,21 +342,40 @@ RT_HD int rt_rank(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi(
 // LDS instructions of one wave execute in issue order, so a read sees an earlier write of another lane: only the
 // compiler has to be kept from reordering across this point (a fence would also wait for the caller's global atomics)
 RT_HD void rt_wave_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+// Reciprocal and square root of the nearest-hit search: hardware estimate (v_rcp_f64 / v_rsq_f64, ~26 bits) plus two
+// Newton steps, ~1 ulp, without the scaling and fix-up instructions of the IEEE sequences (5 and 8 instructions
+// instead of ~14 and ~17).  Out-of-range arguments give NaN where IEEE gives 0 or inf (0, negative, inf): every
+// caller treats all of those as "no root".
+RT_HD double rt_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x), e = fma(-x, y, 1.0);
+    y = fma(y, e, y); e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+RT_HD double rt_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x), g = x * y, h = 0.5 * y, r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    return fma(e, h, g);
+}
 #else
 #define RT_BALLOT(x) ((x) ? 1ull : 0ull)
 #define RT_WAVE 1
 RT_HD int rt_lane() { return 0; }
 RT_HD int rt_rank(unsigned long long) { return 0; }
 RT_HD void rt_wave_sync() {}
+RT_HD double rt_rcp(double x) { return 1.0 / x; }
+RT_HD double rt_sqrt(double x) { return sqrt(x); }
 #endif
 constexpr int TQ_SLOTS = 64, TQ_TORI = 4; // per-wave torus queue: 64 slots of 4 doubles, at most 4 distinct tori pending
 
 // One candidate root l_ of surface n: validity tests of python/RayTracer2.py:316 and the running minimum over
-// (distance, surface order).  Surfaces are normally visited in list order, where "strict <" reproduces :319-321
-// (per-surface argmin, first index wins ties) followed by :362; deferred (torus) candidates arrive out of order and
-// win a tie only against a surface that comes later in the list, which gives the same winner.
-template <bool DEFERRED> RT_HD void try_root(const Geom& G, V3 sp, V3 d, int n, int shape, udptr g, const BRec& b0, int boff, int blen, double lmin, double l_, double s_, bool act, Hit& h) {
-    bool c_ = act && (l_ > lmin) && ((l_ < h.l) || (DEFERRED && l_ == h.l && n < h.surf));
+// (distance, surface order).  The reference takes, per surface, the first smallest root (:319-321) and then replaces
+// the best so far only on strict "<" while walking the list (:362), so among equal distances the surface that comes
+// first in the list wins.  Surfaces are visited here in program order (frames first, see below), not list order:
+// a candidate wins a tie only against a surface that comes later in the list, which gives the same winner.
+RT_HD bool root_wins(double l_, int n, double lmin, const Hit& h) { return (l_ > lmin) && ((l_ < h.l) || (l_ == h.l && n < h.surf)); }
+RT_HD void try_root(const Geom& G, V3 sp, V3 d, int n, int shape, udptr g, const BRec& b0, int boff, int blen, double lmin, double l_, double s_, bool act, Hit& h) {
+    bool c_ = act && root_wins(l_, n, lmin, h);
     if (shape != SH_TORUS) c_ = c_ && (s_ != 0);
     if (RT_ANY(c_)) {
 #ifdef RT_PROFILE
@@ -367,159 +398,497 @@ template <bool DEFERRED> RT_HD void try_root(const Geom& G, V3 sp, V3 d, int n, 
     }
 }
 
-// Nearest valid hit over all surfaces.  Every shape first produces its candidate roots (NaN = none) and the sign of
-// d.normal there; try_root() then applies the validity tests and keeps the running minimum.  `d` is a unit vector
-// (normalised once per step, RayToShape.py:11-14), so the leading coefficient of the sphere quadratic and of the
-// torus quartic is taken as 1.
-//
 // Torus quartics are not solved where they are met: only a few lanes of a wave pass the prefilter of any one torus,
 // but nearly every wave has some lane that does, so solving in place would run the (expensive) solver once per
 // torus per wave at a few percent lane utilisation.  Instead the lanes that need a solve push their depressed
 // quartic into a per-wave queue (G.tq, LDS); when the queue is full, and after the last surface, lanes 0..n-1 solve
-// the n queued quartics in one call and the owners take their roots back.  `act` = this lane carries a live ray; the
-// whole wave must call find_hit together (idle lanes still serve as solver lanes).
-RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, bool act, Hit& h) {
-    h.l = INFINITY; h.surf = -1; h.orient = 0;
+// the n queued quartics in one call and the owners take their roots back.
+struct TorusQ {
+    double* tq;
+    int npend, ntor;              // wave-uniform: slots used, distinct tori pending
+    unsigned long long torpack;   // wave-uniform: 16-bit surface index of each pending torus
+    uint32_t slotpack;            // per lane: 8-bit (slot + 1) for each pending torus, 0 = none
+};
+RT_HD void torus_flush(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, bool act, Hit& h, TorusQ& T) {
+    if (T.npend == 0) return;
+#ifdef RT_PROFILE
+    h.ps += 1;
+    long long tf_ = (long long)__builtin_readcyclecounter();
+#endif
+    rt_wave_sync();
+    for (int j = rt_lane(); j < T.npend; j += RT_WAVE) { // device: one slot per lane
+        double* q = T.tq + 4 * j;
+        double t0 = q[3];
+        Roots4 y = solve_depressed_quartic(q[0], q[1], q[2]);
+        q[0] = y.y0 + t0; q[1] = y.y1 + t0; q[2] = y.y2 + t0; q[3] = y.y3 + t0;
+    }
+    rt_wave_sync();
+#pragma unroll 1
+    for (int k = 0; k < T.ntor; k++) {
+        const int nt = (int)((T.torpack >> (16 * k)) & 0xFFFFull);
+        const uint32_t my = (T.slotpack >> (8 * k)) & 0xFFu;
+        udptr g = G.usurf + nt * ROW + 2;
+        uuptr sm = G.smeta + 4 * nt;
+        const int boff = (int)sm[2], blen = (int)sm[3];
+        const BRec b0 = brec_load(G.urec + (size_t)boff * BREC);
+        const double lmin = (six_last == nt + P.base) ? P.min_travel : 0.0;
+        const double* q = T.tq + 4 * (my ? my - 1 : 0);
+#pragma unroll 1
+        for (int m = 0; m < 4; m++) try_root(G, sp, d, nt, SH_TORUS, g, b0, boff, blen, lmin, my ? q[m] : NAN, 0.0, act, h);
+    }
+    rt_wave_sync();
+#ifdef RT_PROFILE
+    h.pf += (long long)__builtin_readcyclecounter() - tf_;
+#endif
+    T.npend = 0; T.ntor = 0; T.torpack = 0; T.slotpack = 0;
+}
+
+// One surface by the reference's own formulas (RayToPlane/Sphere/Cylinder/Quadsurface/Torus): every shape produces
+// its candidate roots (NaN = none) and the sign of d.normal there; try_root() applies the validity tests and keeps
+// the running minimum.  `d` is a unit vector (normalised once per step, RayToShape.py:11-14), so the leading
+// coefficient of the sphere quadratic and of the torus quartic is taken as 1.
+RT_HD void generic_surface(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, bool act, int n, Hit& h, TorusQ& T) {
     const bool py2 = (P.compat & COMPAT_PY_ROOT2) != 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    double* tq = G.tq;
-#else
-    double tq_host[4 * TQ_SLOTS]; double* tq = tq_host;
-#endif
-    int npend = 0, ntor = 0;             // wave-uniform: slots used, distinct tori pending
-    unsigned long long torpack = 0;      // wave-uniform: 16-bit surface index of each pending torus
-    uint32_t slotpack = 0;               // per lane: 8-bit (slot + 1) for each pending torus, 0 = none
-    for (int n = 0;; n++) {
-        const bool last = n >= G.S;
-        bool flush = last;
-        if (!last) {
-            udptr row = G.usurf + n * ROW;
-            udptr g = row + 2;
-            uuptr sm = G.smeta + 4 * n;
-            const int shape = (int)sm[0], boff = (int)sm[2], blen = (int)sm[3];
-            const BRec b0 = brec_load(G.urec + (size_t)boff * BREC); // first bounds record: on its way while the roots are found
-            const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
-            double l0 = NAN, l1 = NAN, s0 = 0, s1 = 0; // s = d . (outward normal) up to a positive factor
-            int M = 2;
-            if (shape == SH_PLANE) { // RayToPlane.py:35-45
-                V3 pn = ld3(g + 3);
-                double den = dot(d, pn), num = dot(ld3(g) - sp, pn);
-                l0 = num / den; s0 = den; M = 1;
-            } else if (shape == SH_SPHERE) { // RayToSphere.m:72-87 with a = 1: l = -B +- sqrt(B^2 - C)
-                V3 x = sp - ld3(g);
-                double r = g[3], B = dot(d, x), C = dot(x, x) - r * r, D = B * B - C;
-                if (RT_ANY(D >= 0)) {
-                    double sq = sqrt(D); // NaN if D < 0: fails every comparison below
-                    l0 = sq - B; l1 = py2 ? -l0 : -B - sq;
-                    s0 = (B + l0) * r; s1 = (B + l1) * r;
-                }
-            } else if (shape == SH_CYL) { // RayToCylinder.m:84-122
-                V3 ax = ld3(g + 3), x = sp - ld3(g);
-                double r = g[6], xa = dot(x, ax), da = dot(d, ax);
-                V3 u = xa * ax - x, v = da * ax - d;
-                double a = dot(v, v), hb = dot(u, v), c = dot(u, u) - r * r; // hb = b/2
-                if (a != 0) {
-                    double ia = 1.0 / a, sq = sqrt(hb * hb - a * c);
-                    l0 = (sq - hb) * ia; l1 = py2 ? -l0 : (-hb - sq) * ia;
-                } else if (hb != 0) { l0 = l1 = -0.5 * c / hb; }
-                s0 = (hb + l0 * a) * r; s1 = (hb + l1 * a) * r;
-            } else if (shape == SH_QUAD) { // RayToQuadsurface.m:83-123
-                udptr Q = g; V3 Pv = ld3(g + 9); double R = g[12];
-                V3 dQ = { d.x * Q[0] + d.y * Q[3] + d.z * Q[6], d.x * Q[1] + d.y * Q[4] + d.z * Q[7], d.x * Q[2] + d.y * Q[5] + d.z * Q[8] };
-                V3 sQ = { sp.x * Q[0] + sp.y * Q[3] + sp.z * Q[6], sp.x * Q[1] + sp.y * Q[4] + sp.z * Q[7], sp.x * Q[2] + sp.y * Q[5] + sp.z * Q[8] };
-                double a = dot(dQ, d), sQd = dot(sQ, d), dP = dot(d, Pv), b = dP + dot(dQ, sp) + sQd, c = R + dot(sp, Pv) + dot(sQ, sp);
-                bool lin = (b != 0) && (fabs(4 * a * c) < (100 * 2.220446049250313e-16) * (b * b));
-                if (lin) { l0 = -c / b; l1 = -b / a; }
-                else if (a != 0) { double ia = 0.5 / a, sq = sqrt(b * b - 4 * a * c); l0 = (sq - b) * ia; l1 = (-b - sq) * ia; }
-                double g0 = 2 * sQd + dP; // d . (2 pQ + P) = g0 + 2 l a
-                s0 = g0 + 2 * l0 * a; s1 = g0 + 2 * l1 * a;
-            } else if (shape == SH_TORUS) { // RayToTorus.m:88-159
-                M = 0;
-#ifdef RT_PROFILE
-                long long tt_ = (long long)__builtin_readcyclecounter();
-#endif
-                V3 ax = ld3(g + 3), x = sp - ld3(g);
-                double R1 = g[6], r2 = g[7];
-                // The torus lies inside the slab |axial| <= r2 and between the cylinders of radius R1 -+ r2 about its
-                // axis.  Ray parameter interval inside slab, outer cylinder and (lmin, best hit so far); nothing to
-                // solve when it is empty or when the ray stays inside the inner cylinder throughout it (radius^2 is
-                // convex in t: its maximum over an interval is at an end).  r2 is widened by 1e-9 so that rounding
-                // never drops a real root.
-                double re = fabs(r2) * (1 + 1e-9), Ro = fabs(R1) + re, Ri = fabs(R1) - re;
-                double xa0 = dot(x, ax), da = dot(d, ax), xd = dot(x, d), xx = dot(x, x);
-                double ida = 1.0 / da, ta = (-re - xa0) * ida, tb = (re - xa0) * ida;
-                double lo = fmin(ta, tb), hi = fmax(ta, tb);
-                if (da == 0) { bool in = fabs(xa0) <= re; lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; }
-                double qa = 1 - da * da, qb = xd - xa0 * da, qc = xx - xa0 * xa0; // radius^2(t) = qa t^2 + 2 qb t + qc
-                double disc = qb * qb - qa * (qc - Ro * Ro);
-                if (qa > 0) { double iq = 1.0 / qa, sq = sqrt(disc); lo = fmax(lo, (-qb - sq) * iq); hi = fmin(hi, (sq - qb) * iq); }
-                lo = fmax(lo, lmin); hi = fmin(hi, h.l);
-                bool maybe = act && (disc >= 0) && (lo <= hi);
-                if (Ri > 0) maybe = maybe && !(((qa * lo + 2 * qb) * lo + qc < Ri * Ri) && ((qa * hi + 2 * qb) * hi + qc < Ri * Ri));
-                const unsigned long long mb = RT_BALLOT(maybe);
-#ifdef RT_PROFILE
-                h.pm += __popcll(mb);
-#endif
-                if (mb != 0ull) {
-                    const int cnt = __builtin_popcountll(mb);
-                    if (npend + cnt > TQ_SLOTS || ntor == TQ_TORI) { flush = true; n--; } // no room: solve what is queued, then come back
-                    else {
-                        if (maybe) { // depressed quartic about the point of closest approach to the torus centre
-                            int slot = npend + rt_rank(mb);
-                            double t0 = -xd;
-                            V3 xs = x + t0 * d;
-                            double X2 = dot(xs, xs), xa = dot(xs, ax), K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
-                            double* q = tq + 4 * slot;
-                            q[0] = 2 * K - R4 * (1 - da * da); q[1] = 2 * R4 * xa * da; q[2] = K * K - R4 * (X2 - xa * xa); q[3] = t0;
-                            slotpack |= (uint32_t)(slot + 1) << (8 * ntor);
-                        }
-                        torpack |= (unsigned long long)(unsigned)n << (16 * ntor);
-                        ntor++; npend += cnt;
-                    }
-                }
-#ifdef RT_PROFILE
-                h.pt_ += (long long)__builtin_readcyclecounter() - tt_;
-#endif
-            }
-#pragma unroll 1
-            for (int m = 0; m < M; m++) try_root<false>(G, sp, d, n, shape, g, b0, boff, blen, lmin, m == 0 ? l0 : l1, m == 0 ? s0 : s1, act, h);
+    udptr row = G.usurf + n * ROW;
+    udptr g = row + 2;
+    uuptr sm = G.smeta + 4 * n;
+    const int shape = (int)sm[0], boff = (int)sm[2], blen = (int)sm[3];
+    const BRec b0 = brec_load(G.urec + (size_t)boff * BREC); // first bounds record: on its way while the roots are found
+    const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
+    double l0 = NAN, l1 = NAN, s0 = 0, s1 = 0; // s = d . (outward normal) up to a positive factor
+    int M = 2;
+    if (shape == SH_PLANE) { // RayToPlane.py:35-45
+        V3 pn = ld3(g + 3);
+        double den = dot(d, pn), num = dot(ld3(g) - sp, pn);
+        l0 = num / den; s0 = den; M = 1;
+    } else if (shape == SH_SPHERE) { // RayToSphere.m:72-87 with a = 1: l = -B +- sqrt(B^2 - C)
+        V3 x = sp - ld3(g);
+        double r = g[3], B = dot(d, x), C = dot(x, x) - r * r, D = B * B - C;
+        if (RT_ANY(D >= 0)) {
+            double sq = sqrt(D); // NaN if D < 0: fails every comparison below
+            l0 = sq - B; l1 = py2 ? -l0 : -B - sq;
+            s0 = (B + l0) * r; s1 = (B + l1) * r;
         }
-        if (flush) {
-            if (npend > 0) {
+    } else if (shape == SH_CYL) { // RayToCylinder.m:84-122
+        V3 ax = ld3(g + 3), x = sp - ld3(g);
+        double r = g[6], xa = dot(x, ax), da = dot(d, ax);
+        V3 u = xa * ax - x, v = da * ax - d;
+        double a = dot(v, v), hb = dot(u, v), c = dot(u, u) - r * r; // hb = b/2
+        if (a != 0) {
+            double ia = 1.0 / a, sq = sqrt(hb * hb - a * c);
+            l0 = (sq - hb) * ia; l1 = py2 ? -l0 : (-hb - sq) * ia;
+        } else if (hb != 0) { l0 = l1 = -0.5 * c / hb; }
+        s0 = (hb + l0 * a) * r; s1 = (hb + l1 * a) * r;
+    } else if (shape == SH_QUAD) { // RayToQuadsurface.m:83-123
+        udptr Q = g; V3 Pv = ld3(g + 9); double R = g[12];
+        V3 dQ = { d.x * Q[0] + d.y * Q[3] + d.z * Q[6], d.x * Q[1] + d.y * Q[4] + d.z * Q[7], d.x * Q[2] + d.y * Q[5] + d.z * Q[8] };
+        V3 sQ = { sp.x * Q[0] + sp.y * Q[3] + sp.z * Q[6], sp.x * Q[1] + sp.y * Q[4] + sp.z * Q[7], sp.x * Q[2] + sp.y * Q[5] + sp.z * Q[8] };
+        double a = dot(dQ, d), sQd = dot(sQ, d), dP = dot(d, Pv), b = dP + dot(dQ, sp) + sQd, c = R + dot(sp, Pv) + dot(sQ, sp);
+        bool lin = (b != 0) && (fabs(4 * a * c) < (100 * 2.220446049250313e-16) * (b * b));
+        if (lin) { l0 = -c / b; l1 = -b / a; }
+        else if (a != 0) { double ia = 0.5 / a, sq = sqrt(b * b - 4 * a * c); l0 = (sq - b) * ia; l1 = (-b - sq) * ia; }
+        double g0 = 2 * sQd + dP; // d . (2 pQ + P) = g0 + 2 l a
+        s0 = g0 + 2 * l0 * a; s1 = g0 + 2 * l1 * a;
+    } else if (shape == SH_TORUS) { // RayToTorus.m:88-159
+        M = 0;
 #ifdef RT_PROFILE
-                h.ps += 1;
-                long long tf_ = (long long)__builtin_readcyclecounter();
+        long long tt_ = (long long)__builtin_readcyclecounter();
 #endif
-                rt_wave_sync();
-                for (int j = rt_lane(); j < npend; j += RT_WAVE) { // device: one slot per lane
-                    double* q = tq + 4 * j;
-                    double t0 = q[3];
-                    Roots4 y = solve_depressed_quartic(q[0], q[1], q[2]);
-                    q[0] = y.y0 + t0; q[1] = y.y1 + t0; q[2] = y.y2 + t0; q[3] = y.y3 + t0;
-                }
-                rt_wave_sync();
-#pragma unroll 1
-                for (int k = 0; k < ntor; k++) {
-                    const int nt = (int)((torpack >> (16 * k)) & 0xFFFFull);
-                    const uint32_t my = (slotpack >> (8 * k)) & 0xFFu;
-                    udptr g = G.usurf + nt * ROW + 2;
-                    uuptr sm = G.smeta + 4 * nt;
-                    const int boff = (int)sm[2], blen = (int)sm[3];
-                    const BRec b0 = brec_load(G.urec + (size_t)boff * BREC);
-                    const double lmin = (six_last == nt + P.base) ? P.min_travel : 0.0;
-                    const double* q = tq + 4 * (my ? my - 1 : 0);
-#pragma unroll 1
-                    for (int m = 0; m < 4; m++) try_root<true>(G, sp, d, nt, SH_TORUS, g, b0, boff, blen, lmin, my ? q[m] : NAN, 0.0, act, h);
-                }
-                rt_wave_sync();
+        V3 ax = ld3(g + 3), x = sp - ld3(g);
+        double R1 = g[6], r2 = g[7];
+        // The torus lies inside the slab |axial| <= r2 and between the cylinders of radius R1 -+ r2 about its
+        // axis.  Ray parameter interval inside slab, outer cylinder and (lmin, best hit so far); nothing to
+        // solve when it is empty or when the ray stays inside the inner cylinder throughout it (radius^2 is
+        // convex in t: its maximum over an interval is at an end).  r2 is widened by 1e-9 so that rounding
+        // never drops a real root.
+        double re = fabs(r2) * (1 + 1e-9), Ro = fabs(R1) + re, Ri = fabs(R1) - re;
+        double xa0 = dot(x, ax), da = dot(d, ax), xd = dot(x, d), xx = dot(x, x);
+        double ida = 1.0 / da, ta = (-re - xa0) * ida, tb = (re - xa0) * ida;
+        double lo = fmin(ta, tb), hi = fmax(ta, tb);
+        if (da == 0) { bool in = fabs(xa0) <= re; lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; }
+        double qa = 1 - da * da, qb = xd - xa0 * da, qc = xx - xa0 * xa0; // radius^2(t) = qa t^2 + 2 qb t + qc
+        double disc = qb * qb - qa * (qc - Ro * Ro);
+        if (qa > 0) { double iq = 1.0 / qa, sq = sqrt(disc); lo = fmax(lo, (-qb - sq) * iq); hi = fmin(hi, (sq - qb) * iq); }
+        lo = fmax(lo, lmin); hi = fmin(hi, h.l);
+        bool maybe = act && (disc >= 0) && (lo <= hi);
+        if (Ri > 0) maybe = maybe && !(((qa * lo + 2 * qb) * lo + qc < Ri * Ri) && ((qa * hi + 2 * qb) * hi + qc < Ri * Ri));
+        const unsigned long long mb = RT_BALLOT(maybe);
 #ifdef RT_PROFILE
-                h.pf += (long long)__builtin_readcyclecounter() - tf_;
+        h.pm += __popcll(mb);
 #endif
-                npend = 0; ntor = 0; torpack = 0; slotpack = 0;
+        if (mb != 0ull) {
+            const int cnt = __builtin_popcountll(mb);
+            if (T.npend + cnt > TQ_SLOTS || T.ntor == TQ_TORI) torus_flush(G, P, sp, d, six_last, act, h, T); // no room: solve what is queued first
+            if (maybe) { // depressed quartic about the point of closest approach to the torus centre
+                int slot = T.npend + rt_rank(mb);
+                double t0 = -xd;
+                V3 xs = x + t0 * d;
+                double X2 = dot(xs, xs), xa = dot(xs, ax), K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
+                double* q = T.tq + 4 * slot;
+                q[0] = 2 * K - R4 * (1 - da * da); q[1] = 2 * R4 * xa * da; q[2] = K * K - R4 * (X2 - xa * xa); q[3] = t0;
+                T.slotpack |= (uint32_t)(slot + 1) << (8 * T.ntor);
             }
-            if (last) break;
+            T.torpack |= (unsigned long long)(unsigned)n << (16 * T.ntor);
+            T.ntor++; T.npend += cnt;
+        }
+#ifdef RT_PROFILE
+        h.pt_ += (long long)__builtin_readcyclecounter() - tt_;
+#endif
+    }
+#pragma unroll 1
+    for (int m = 0; m < M; m++) try_root(G, sp, d, n, shape, g, b0, boff, blen, lmin, m == 0 ? l0 : l1, m == 0 ? s0 : s1, act, h);
+}
+
+// Frame program.  Detector geometries are overwhelmingly coaxial: in the jar geometry 26 of 39 surfaces share the z
+// axis and the other 13 the camera axis.  build_program() groups the surfaces whose own axis (cylinder/torus axis,
+// plane normal) lies on a common line ("frame": point c0, unit vector a^), and spheres / quadrics of revolution
+// centred on that line.  Per ray and frame the kernel computes once
+//     x = sp - c0, xa = x.a^, da = d.a^, u = xa a^ - x, v = da a^ - d, a = v.v, hb = u.v, uu = u.u, xd = x.d, xx = x.x
+// (the cylinder quantities of RayToCylinder.m:84-100) and every member surface then costs a handful of operations:
+//     cylinder r        : c = uu - r^2, l = (-hb +- sqrt(hb^2 - a c)) / a                     (RayToCylinder.m:101-105)
+//     plane  n^ = +-a^  : l = (ka - xa) / da, ka = (p0 - c0).a^                                (RayToPlane.m:78)
+//     sphere c0 + t a^  : B = xd - t da, C = xx - 2 t xa + t^2 - r^2, l = -B +- sqrt(B^2 - C)  (RayToSphere.m:72-77)
+//     quadric alpha(x^2 + y^2) + gamma z^2 + pa z + R' in frame coordinates                   (RayToQuadsurface.m:83-107)
+// The sign of d.normal at the roots of a quadratic is the sign of +-sqrt(discriminant), so orientations cost nothing.
+// Bounds that are conjunctions of ranges of the frame's own coordinates - axial (xa + l da), radial^2
+// ((a l + 2 hb) l + uu) and distance^2 from a point of the axis - are evaluated from those quantities without
+// forming the hit point; whatever else a bounds program contains stays a (residual) generic program evaluated at
+// the point.  Surfaces that fit no frame run generic_surface().  Everything is wave-uniform control flow over
+// 128-byte records read with scalar loads.
+constexpr int PREC = 16; // doubles per program record
+enum { PK_FRAME = 0, PK_PLANE = 1, PK_SPHERE = 2, PK_CYL = 3, PK_QUAD = 4, PK_GENERIC = 5, PK_TORUS = 6 };
+enum { FA_AXIAL = 0, FA_RADIAL2 = 1, FA_DIST2 = 2 };
+// record word 0 (64-bit integer): bits 0-3 kind, 4-15 surface number, 16-17 number of inline range atoms,
+// 20+4j..23+4j atom j: bits 0-1 coordinate (FA_*), 2 lower bound inclusive, 3 upper bound inclusive;
+// 32-51 first record / 52-63 number of records of the residual bounds program.
+// words 1-6: constants of the kind; words 7+3j..9+3j: atom j {lo, hi, t}.
+//   PK_FRAME c0(3) a^(3) | PK_PLANE ka, sigma | PK_CYL r, r^2 | PK_SPHERE t, r, t^2 - r^2 | PK_QUAD alpha, gamma, pa, R'
+//   PK_TORUS t, R1, r2, centre(3)
+struct FrameQ { double xa, da, ida, a, ia, hb, uu, xd, xx; int sda; };
+struct PRec { double w[PREC]; };
+template <class Ptr> RT_HD PRec prec_load(Ptr r) { PRec p; for (int j = 0; j < PREC; j++) p.w[j] = r[j]; return p; }
+
+RT_HD double frame_coord(const FrameQ& F, uint32_t coord, double t, double l) {
+    if (coord == FA_AXIAL) return F.xa + l * F.da;
+    if (coord == FA_RADIAL2) return (F.a * l + 2 * F.hb) * l + F.uu;
+    return (l + 2 * (F.xd - t * F.da)) * l + (F.xx - 2 * t * F.xa + t * t);
+}
+// candidate tests without short-circuit evaluation: the operands are cheap and per lane, a branch per "&&" is not
+RT_HD bool wins_nb(double l_, double lmin, double bl, bool first) { return (l_ > lmin) & ((l_ < bl) | ((l_ == bl) & first)); }
+RT_HD bool in_range(double v, double lo, double hi, uint32_t am) { return ((am & 4u) ? (v >= lo) : (v > lo)) & ((am & 8u) ? (v <= hi) : (v < hi)); }
+
+// Roots l0, l1 of frame member `R` (orientations o0, o1; ok0, ok1 = root exists and is not tangent): range atoms,
+// residual bounds, running minimum.
+RT_HD void frame_candidates(const Geom& G, const Prm& P, const FrameQ& F, const PRec& R, uint32_t mlo, uint32_t mhi, V3 sp, V3 d, int six_last, bool act,
+                            double l0, double l1, int o0, int o1, bool ok0, bool ok1, Hit& h) {
+    const int n = (int)((mlo >> 4) & 0xFFFu);
+    const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
+    const bool first = n < h.surf;
+    bool c0_ = act & ok0 & wins_nb(l0, lmin, h.l, first), c1_ = act & ok1 & wins_nb(l1, lmin, h.l, first);
+    const uint32_t na = (mlo >> 16) & 3u;
+    if (na > 0) { const uint32_t am = (mlo >> 20) & 15u; c0_ = c0_ & in_range(frame_coord(F, am & 3u, R.w[9], l0), R.w[7], R.w[8], am); c1_ = c1_ & in_range(frame_coord(F, am & 3u, R.w[9], l1), R.w[7], R.w[8], am); }
+    if (na > 1) { const uint32_t am = (mlo >> 24) & 15u; c0_ = c0_ & in_range(frame_coord(F, am & 3u, R.w[12], l0), R.w[10], R.w[11], am); c1_ = c1_ & in_range(frame_coord(F, am & 3u, R.w[12], l1), R.w[10], R.w[11], am); }
+    if (na > 2) { const uint32_t am = (mlo >> 28) & 15u; c0_ = c0_ & in_range(frame_coord(F, am & 3u, R.w[15], l0), R.w[13], R.w[14], am); c1_ = c1_ & in_range(frame_coord(F, am & 3u, R.w[15], l1), R.w[13], R.w[14], am); }
+    const int blen = (int)(mhi >> 20);
+    if (blen != 0) { // residual bounds program, at the point
+        const int boff = (int)(mhi & 0xFFFFFu);
+        if (RT_ANY(c0_)) { if (c0_) c0_ = inbounds(G, brec_load(G.urec + (size_t)boff * BREC), boff, blen, sp + l0 * d); }
+        if (RT_ANY(c1_)) { if (c1_) c1_ = inbounds(G, brec_load(G.urec + (size_t)boff * BREC), boff, blen, sp + l1 * d); }
+    }
+    // same surface: the first smallest root (RayTracer2.py:319-321)
+    const bool take1 = c1_ & (!c0_ | (l1 < l0)), any = c0_ | c1_;
+    const double ln = take1 ? l1 : l0; const int on = take1 ? o1 : o0;
+    h.l = any ? ln : h.l; h.surf = any ? n : h.surf; h.orient = any ? on : h.orient;
+}
+
+// Torus queue of frame members: slot = {p, q, r, t0} in, {l0..l3, sign bits of f'(l)} out (6 doubles per slot).
+constexpr int TQ_STRIDE = 6;
+RT_HD void frame_torus_flush(const Geom& G, const Prm& P, const FrameQ& F, udptr prog, V3 sp, V3 d, int six_last, bool act, Hit& h, TorusQ& T) {
+    if (T.npend == 0) return;
+    rt_wave_sync();
+    for (int j = rt_lane(); j < T.npend; j += RT_WAVE) { // device: one slot per lane
+        double* q = T.tq + TQ_STRIDE * j;
+        const double p_ = q[0], q_ = q[1], t0 = q[3];
+        Roots4 y = solve_depressed_quartic(p_, q_, q[2]);
+        // d.normal at a root has the sign of f'(y) = 4 y^3 + 2 p y + q (times sign(R1 r2), applied by the owner)
+        uint64_t sg = 0;
+        { double f = (4 * y.y0 * y.y0 + 2 * p_) * y.y0 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)); }
+        { double f = (4 * y.y1 * y.y1 + 2 * p_) * y.y1 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)) << 2; }
+        { double f = (4 * y.y2 * y.y2 + 2 * p_) * y.y2 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)) << 4; }
+        { double f = (4 * y.y3 * y.y3 + 2 * p_) * y.y3 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)) << 6; }
+        q[0] = y.y0 + t0; q[1] = y.y1 + t0; q[2] = y.y2 + t0; q[3] = y.y3 + t0;
+        double sd; memcpy(&sd, &sg, 8); q[4] = sd;
+    }
+    rt_wave_sync();
+#pragma unroll 1
+    for (int k = 0; k < T.ntor; k++) {
+        const int ri = (int)((T.torpack >> (16 * k)) & 0xFFFFull); // program record of this torus
+        const uint32_t my = (T.slotpack >> (8 * k)) & 0xFFu;
+        const PRec R = prec_load(prog + (size_t)ri * PREC);
+        uint64_t meta; memcpy(&meta, &R.w[0], 8);
+        const uint32_t mlo = (uint32_t)meta, mhi = (uint32_t)(meta >> 32);
+        const double* q = T.tq + TQ_STRIDE * (my ? my - 1 : 0);
+        uint64_t sg; { double sd = q[4]; memcpy(&sg, &sd, 8); }
+        const int flip = (R.w[2] * R.w[3] < 0) ? -1 : 1;
+        const bool mine = act & (my != 0);
+        // roots in pairs; a NaN root fails every comparison
+#pragma unroll 1
+        for (int m = 0; m < 4; m += 2) {
+            const uint32_t s0 = (uint32_t)(sg >> (2 * m)) & 3u, s1 = (uint32_t)(sg >> (2 * m + 2)) & 3u;
+            const int o0 = -flip * (s0 == 1u ? 1 : -1), o1 = -flip * (s1 == 1u ? 1 : -1);
+            frame_candidates(G, P, F, R, mlo, mhi, sp, d, six_last, mine, q[m], q[m + 1], o0, o1, s0 != 0u, s1 != 0u, h);
         }
     }
+    rt_wave_sync();
+    T.npend = 0; T.ntor = 0; T.torpack = 0; T.slotpack = 0;
+}
+
+// GENERIC = false: the program has no PK_GENERIC record (the caller checked); that code is then not compiled in, which
+// is what keeps the register count of the nearest-hit kernel low.
+template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, V3 sp, V3 d, int six_last, bool act, Hit& h) {
+    h.l = INFINITY; h.surf = -1; h.orient = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    TorusQ T{ G.tq, 0, 0, 0ull, 0u };
+#else
+    double tq_host[TQ_STRIDE * TQ_SLOTS]; TorusQ T{ tq_host, 0, 0, 0ull, 0u };
+#endif
+    TorusQ TG = T; // generic tori (separate bookkeeping, same LDS: flushed before a frame torus is queued and vice versa)
+    FrameQ F = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int i = 0; i < G.nprog; i++) {
+        const PRec R = prec_load(G.uprog + (size_t)i * PREC);
+        uint64_t meta; memcpy(&meta, &R.w[0], 8);
+        const uint32_t mlo = (uint32_t)meta, mhi = (uint32_t)(meta >> 32);
+        const uint32_t kind = mlo & 15u;
+        if (kind == PK_FRAME) {
+            frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T); // queued tori belong to the frame that ends here
+            V3 c0 = ld3(R.w + 1), ax = ld3(R.w + 4), x = sp - c0;
+            F.xa = dot(x, ax); F.da = dot(d, ax);
+            V3 u = F.xa * ax - x, v = F.da * ax - d;
+            F.a = dot(v, v); F.hb = dot(u, v); F.uu = dot(u, u); F.xd = dot(x, d); F.xx = dot(x, x);
+            F.ida = rt_rcp(F.da); F.ia = rt_rcp(F.a); F.sda = isgn(F.da);
+            continue;
+        }
+        if (kind == PK_GENERIC) {
+            if (GENERIC) {
+                if (T.npend) frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T);
+                generic_surface(G, P, sp, d, six_last, act, (int)((mlo >> 4) & 0xFFFu), h, TG);
+            }
+            continue;
+        }
+        double l0 = NAN, l1 = NAN; int o0 = 0, o1 = 0; bool ok0 = false, ok1 = false;
+        if (kind == PK_PLANE) {
+            l0 = (R.w[1] - F.xa) * F.ida; o0 = -(int)R.w[2] * F.sda; ok0 = F.sda != 0;
+        } else if (kind == PK_CYL) {
+            const double rad = R.w[1], c = F.uu - R.w[2], disc = F.hb * F.hb - F.a * c;
+            const double sq = rt_sqrt(disc);
+            l0 = (sq - F.hb) * F.ia; l1 = (-F.hb - sq) * F.ia;
+            o0 = rad > 0 ? -1 : 1; o1 = -o0; ok0 = ok1 = sq > 0;
+            if (RT_ANY(F.a == 0)) { // ray parallel to the axis: RayToCylinder.m:106-112
+                if (F.a == 0) { l0 = l1 = (F.hb != 0) ? -0.5 * c / F.hb : NAN; o0 = o1 = -isgn(F.hb * rad); ok0 = o0 != 0; ok1 = false; }
+            }
+        } else if (kind == PK_SPHERE) {
+            const double t = R.w[1], rad = R.w[2], B = F.xd - t * F.da, C = (F.xx - 2 * t * F.xa) + R.w[3], D = B * B - C;
+            const double sq = rt_sqrt(D);
+            l0 = sq - B; l1 = -B - sq;
+            o0 = rad > 0 ? -1 : 1; o1 = -o0; ok0 = ok1 = sq > 0;
+        } else if (kind == PK_QUAD) {
+            const double al = R.w[1], ga = R.w[2], pa = R.w[3];
+            const double aq = al * F.a + ga * F.da * F.da, b = 2 * (al * F.hb + ga * F.xa * F.da) + pa * F.da, c = al * F.uu + (ga * F.xa + pa) * F.xa + R.w[4];
+            const double sq = rt_sqrt(b * b - 4 * aq * c), ia = 0.5 * rt_rcp(aq);
+            l0 = (sq - b) * ia; l1 = (-b - sq) * ia;
+            o0 = -1; o1 = 1; ok0 = ok1 = sq > 0; // d.(2pQ + P) = b + 2 l aq = +-sqrt(discriminant)
+            const bool lin = (b != 0) & (fabs(4 * aq * c) < (100 * 2.220446049250313e-16) * (b * b));
+            if (RT_ANY(lin | (aq == 0))) {
+                if (lin) { l0 = -c / b; l1 = -b / aq; o0 = -isgn(b + 2 * l0 * aq); o1 = -isgn(b + 2 * l1 * aq); ok0 = o0 != 0; ok1 = o1 != 0; }
+                else if (aq == 0) { ok0 = ok1 = false; }
+            }
+        } else { // PK_TORUS: RayToTorus.m:88-159; prefilter and quartic as in generic_surface(), from the frame's quantities
+            const double t = R.w[1], R1 = R.w[2], r2 = R.w[3];
+            const int n = (int)((mlo >> 4) & 0xFFFu);
+            const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0;
+            const double re = fabs(r2) * (1 + 1e-9), Ro = fabs(R1) + re, Ri = fabs(R1) - re;
+            const double xa0 = F.xa - t;
+            const double ta = (-re - xa0) * F.ida, tb = (re - xa0) * F.ida;
+            double lo = fmin(ta, tb), hi = fmax(ta, tb);
+            if (RT_ANY(F.sda == 0)) { if (F.sda == 0) { const bool in = fabs(xa0) <= re; lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; } }
+            const double disc = F.hb * F.hb - F.a * (F.uu - Ro * Ro), sq = rt_sqrt(disc);
+            const bool qpos = F.a > 0;
+            lo = qpos ? fmax(lo, (-F.hb - sq) * F.ia) : lo; hi = qpos ? fmin(hi, (sq - F.hb) * F.ia) : hi;
+            lo = fmax(lo, lmin); hi = fmin(hi, h.l);
+            bool maybe = act & (disc >= 0) & (lo <= hi);
+            if (Ri > 0) maybe = maybe & !(((F.a * lo + 2 * F.hb) * lo + F.uu < Ri * Ri) & ((F.a * hi + 2 * F.hb) * hi + F.uu < Ri * Ri));
+            const unsigned long long mb = RT_BALLOT(maybe);
+            if (mb != 0ull) {
+                const int cnt = __builtin_popcountll(mb);
+                if (GENERIC && TG.npend) torus_flush(G, P, sp, d, six_last, act, h, TG);
+                if (T.npend + cnt > TQ_SLOTS || T.ntor == TQ_TORI) frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T);
+                if (maybe) { // depressed quartic about the point of closest approach to the torus centre
+                    const int slot = T.npend + rt_rank(mb);
+                    V3 x = sp - ld3(R.w + 4);
+                    const double t0 = -dot(x, d);
+                    V3 xs = x + t0 * d;
+                    const double X2 = dot(xs, xs), xas = xa0 + t0 * F.da, K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
+                    double* q = T.tq + TQ_STRIDE * slot;
+                    q[0] = 2 * K - R4 * F.a; q[1] = 2 * R4 * xas * F.da; q[2] = K * K - R4 * (X2 - xas * xas); q[3] = t0;
+                    T.slotpack |= (uint32_t)(slot + 1) << (8 * T.ntor);
+                }
+                T.torpack |= (unsigned long long)(unsigned)i << (16 * T.ntor);
+                T.ntor++; T.npend += cnt;
+            }
+            continue;
+        }
+        frame_candidates(G, P, F, R, mlo, mhi, sp, d, six_last, act, l0, l1, o0, o1, ok0, ok1, h);
+    }
+    frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T);
+    if (GENERIC) torus_flush(G, P, sp, d, six_last, act, h, TG);
+}
+
+// ---------------------------------------------------------------------------------------------- frame program (host)
+// Host: surface table + public bounds programs -> the records find_hit() walks.  frames = false gives one
+// PK_GENERIC record per surface in list order (the reference's formulas throughout; used for COMPAT_PY_ROOT2).
+// Tolerances: a surface joins a frame only if the misfit (angle between axes, distance of its centre from the
+// frame's line, deviation of a quadric from one of revolution) is below 1e-13 relative, far inside the 1e-9 the
+// parity tests allow; anything else stays generic.
+namespace hostprog {
+struct V { double x, y, z; };
+static inline V mk(const double* p) { return V{ p[0], p[1], p[2] }; }
+static inline double dt(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V sub(V a, V b) { return V{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+static inline V add(V a, V b) { return V{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+static inline V mul(double s, V a) { return V{ s * a.x, s * a.y, s * a.z }; }
+static inline V crs(V a, V b) { return V{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+static inline double nrm(V a) { return sqrt(dt(a, a)); }
+struct Frame { V c0, ax; int members; };
+struct Range { bool used; double lo, hi; bool ilo, ihi; double t; };
+constexpr double TOL = 1e-13;
+static inline bool parallel(V a, V b, double& sigma) { sigma = dt(a, b) >= 0 ? 1.0 : -1.0; return nrm(crs(a, b)) <= TOL; }
+static inline bool on_line(const Frame& f, V p) { V dp = sub(p, f.c0); V perp = sub(dp, mul(dt(dp, f.ax), f.ax)); return nrm(perp) <= 1e-12 * (1.0 + nrm(dp)); }
+static inline V mat(const double* S, V v) { return V{ S[0] * v.x + S[1] * v.y + S[2] * v.z, S[3] * v.x + S[4] * v.y + S[5] * v.z, S[6] * v.x + S[7] * v.y + S[8] * v.z }; }
+// x'Sx + b.x (S symmetric) as alpha |x_perp|^2 + gamma xa^2 + pa xa + k0 in frame coordinates, if it is of that form
+static inline bool revolution_form(const Frame& f, const double* S, V b, double& alpha, double& gamma, double& pa, double& k0) {
+    V e1 = crs(f.ax, fabs(f.ax.x) < 0.9 ? V{ 1, 0, 0 } : V{ 0, 1, 0 }); e1 = mul(1.0 / nrm(e1), e1);
+    V e2 = crs(f.ax, e1);
+    double scale = 0; for (int i = 0; i < 9; i++) scale = fmax(scale, fabs(S[i]));
+    if (scale == 0) return false;
+    V s1 = mat(S, e1), s2 = mat(S, e2), sa = mat(S, f.ax);
+    alpha = dt(e1, s1); gamma = dt(f.ax, sa);
+    if (nrm(sub(s1, mul(alpha, e1))) > TOL * scale || nrm(sub(s2, mul(alpha, e2))) > TOL * scale || nrm(sub(sa, mul(gamma, f.ax))) > TOL * scale) return false;
+    V w = add(mul(2.0, mat(S, f.c0)), b); // gradient on the axis line must be axial
+    double wa = dt(w, f.ax);
+    if (nrm(sub(w, mul(wa, f.ax))) > TOL * (scale * (1.0 + nrm(f.c0)) + nrm(b))) return false;
+    pa = wa; k0 = dt(f.c0, mat(S, f.c0)) + dt(b, f.c0);
+    return true;
+}
+} // namespace hostprog
+
+RT_HOST static inline void build_program(const double* table, int S, const double* atoms, const uint32_t* code, bool frames_on,
+                                         std::vector<double>& recs, const std::vector<uint32_t>& smeta, std::vector<double>& prog) {
+    using namespace hostprog;
+    prog.clear();
+    auto put = [&](uint64_t meta, const double* w, int nw) -> size_t {
+        size_t at = prog.size(); prog.resize(at + PREC, 0.0);
+        memcpy(&prog[at], &meta, 8);
+        for (int j = 0; j < nw; j++) prog[at + 1 + j] = w[j];
+        return at;
+    };
+    std::vector<Frame> frames; std::vector<int> fr(S > 0 ? S : 1, -1); std::vector<double> sg(S > 0 ? S : 1, 1.0);
+    if (frames_on) {
+        // frames come from the surfaces that have an axis line of their own
+        for (int s = 0; s < S; s++) {
+            const double* r = table + (size_t)s * ROW; const int shape = (int)r[0];
+            if (shape != SH_CYL && shape != SH_TORUS) continue;
+            V c = mk(r + 2), ax = mk(r + 5); double sig; bool found = false;
+            if (fabs(nrm(ax) - 1.0) > 1e-12) continue;
+            for (size_t f = 0; f < frames.size() && !found; f++) if (parallel(frames[f].ax, ax, sig) && on_line(frames[f], c)) { found = true; fr[s] = (int)f; sg[s] = sig; }
+            if (!found) { frames.push_back(Frame{ c, ax, 0 }); fr[s] = (int)frames.size() - 1; }
+        }
+        for (int s = 0; s < S; s++) {
+            const double* r = table + (size_t)s * ROW; const int shape = (int)r[0]; double sig;
+            if (shape == SH_PLANE) { V nn = mk(r + 5); if (fabs(nrm(nn) - 1.0) <= 1e-12) for (size_t f = 0; f < frames.size() && fr[s] < 0; f++) if (parallel(frames[f].ax, nn, sig)) { fr[s] = (int)f; sg[s] = sig; } }
+            else if (shape == SH_SPHERE) { for (size_t f = 0; f < frames.size() && fr[s] < 0; f++) if (on_line(frames[f], mk(r + 2))) fr[s] = (int)f; }
+            else if (shape == SH_QUAD) {
+                const double* Q = r + 2; bool sym = Q[1] == Q[3] && Q[2] == Q[6] && Q[5] == Q[7];
+                double al, ga, pa, k0;
+                for (size_t f = 0; sym && f < frames.size() && fr[s] < 0; f++) if (revolution_form(frames[f], Q, mk(r + 11), al, ga, pa, k0)) fr[s] = (int)f;
+            }
+        }
+        for (int s = 0; s < S; s++) if (fr[s] >= 0) frames[fr[s]].members++;
+        for (int s = 0; s < S; s++) if (fr[s] >= 0 && frames[fr[s]].members < 2) fr[s] = -1; // a frame must pay for itself
+    }
+    // bounds of a frame member: conjunction of ranges of frame coordinates (inline) + residual generic program
+    auto member_bounds = [&](int s, const Frame& f, uint64_t& meta, double* aw) {
+        const double* r = table + (size_t)s * ROW; const int off = (int)r[27], len = (int)r[28];
+        std::vector<uint32_t> conj; bool pure = true; int depth = 0;
+        for (int i = off; i < off + len && pure; i++) { const uint32_t op = code[i] >> 24; if (op == 1) { conj.push_back(code[i]); depth++; } else if (op == 2) depth--; else pure = false; }
+        if (len == 0) return;
+        if (!pure || depth != 1) { meta |= ((uint64_t)smeta[4 * s + 2] << 32) | ((uint64_t)smeta[4 * s + 3] << 52); return; }
+        std::vector<Range> rg; std::vector<int> rkind; std::vector<uint32_t> rest;
+        auto narrow = [&](int kind, double t, bool upper, double bound, bool incl) {
+            size_t j = 0; for (; j < rg.size(); j++) if (rkind[j] == kind && (kind != FA_DIST2 || rg[j].t == t)) break;
+            if (j == rg.size()) { if (rg.size() == 3) return false; rg.push_back(Range{ true, -INFINITY, INFINITY, false, false, t }); rkind.push_back(kind); }
+            Range& R = rg[j];
+            if (upper) { if (bound < R.hi || (bound == R.hi && !incl)) { R.hi = bound; R.ihi = incl; } }
+            else { if (bound > R.lo || (bound == R.lo && !incl)) { R.lo = bound; R.ilo = incl; } }
+            return true;
+        };
+        for (uint32_t ins : conj) {
+            const double* a = atoms + (size_t)(ins & 0xFFFFFFu) * ATOM; const int kind = (int)a[0], cmp = (int)a[1]; const double rhs = a[2];
+            bool done = false;
+            if (cmp <= 3 && (kind == 3 || kind == 1)) { // linear: c.p cmp rhs
+                V c = kind == 3 ? V{ (int)a[3] == 0 ? 1.0 : 0.0, (int)a[3] == 1 ? 1.0 : 0.0, (int)a[3] == 2 ? 1.0 : 0.0 } : V{ a[9], a[10], a[11] };
+                const double lam = dt(c, f.ax);
+                if (lam != 0 && nrm(sub(c, mul(lam, f.ax))) <= TOL * nrm(c)) { // c.p = lam (xa + c0.a^)
+                    const double bound = rhs / lam - dt(f.c0, f.ax); bool upper = (cmp == 0 || cmp == 1); if (lam < 0) upper = !upper;
+                    done = narrow(FA_AXIAL, 0.0, upper, bound, cmp == 1 || cmp == 3);
+                }
+            } else if (cmp <= 3 && kind == 0) { // quadratic: p'Ap + b.p cmp rhs
+                const double A[9] = { a[3], 0.5 * a[6], 0.5 * a[7], 0.5 * a[6], a[4], 0.5 * a[8], 0.5 * a[7], 0.5 * a[8], a[5] }; V b = V{ a[9], a[10], a[11] };
+                double al, ga, pa, k0;
+                if (revolution_form(f, A, b, al, ga, pa, k0)) {
+                    double scale = fmax(fabs(al), fabs(ga));
+                    if (al != 0 && fabs(ga) <= TOL * scale && fabs(pa) <= TOL * scale * (1.0 + nrm(f.c0))) { // al |x_perp|^2 + k0
+                        bool upper = (cmp == 0 || cmp == 1); if (al < 0) upper = !upper;
+                        done = narrow(FA_RADIAL2, 0.0, upper, (rhs - k0) / al, cmp == 1 || cmp == 3);
+                    } else if (al != 0 && fabs(ga - al) <= TOL * scale) { // al (|x_perp|^2 + xa^2) + pa xa + k0 = al |x - t a^|^2 + k0 - al t^2
+                        const double t = -pa / (2 * al); bool upper = (cmp == 0 || cmp == 1); if (al < 0) upper = !upper;
+                        done = narrow(FA_DIST2, t, upper, (rhs - k0) / al + t * t, cmp == 1 || cmp == 3);
+                    }
+                }
+            }
+            if (!done) rest.push_back(ins);
+        }
+        meta |= (uint64_t)rg.size() << 16;
+        for (size_t j = 0; j < rg.size(); j++) {
+            meta |= (uint64_t)((uint32_t)rkind[j] | (rg[j].ilo ? 4u : 0u) | (rg[j].ihi ? 8u : 0u)) << (20 + 4 * j);
+            aw[3 * j] = rg[j].lo; aw[3 * j + 1] = rg[j].hi; aw[3 * j + 2] = rg[j].t;
+        }
+        if (!rest.empty()) {
+            std::vector<uint32_t> c2;
+            for (size_t j = 0; j < rest.size(); j++) { c2.push_back(rest[j]); if (j) c2.push_back(2u << 24); }
+            const size_t first = emit_bounds_program(c2.data(), (int)c2.size(), atoms, recs), cnt = recs.size() / BREC - first;
+            meta |= ((uint64_t)first << 32) | ((uint64_t)cnt << 52);
+        }
+    };
+    for (size_t f = 0; f < frames.size(); f++) {
+        if (frames[f].members < 2) continue;
+        const Frame& F = frames[f];
+        { double w[6] = { F.c0.x, F.c0.y, F.c0.z, F.ax.x, F.ax.y, F.ax.z }; put((uint64_t)PK_FRAME, w, 6); }
+        for (int s = 0; s < S; s++) {
+            if (fr[s] != (int)f) continue;
+            const double* r = table + (size_t)s * ROW; const int shape = (int)r[0];
+            double w[PREC - 1]; for (int j = 0; j < PREC - 1; j++) w[j] = 0.0;
+            uint64_t meta = (uint64_t)((uint32_t)s << 4);
+            if (shape == SH_PLANE) { meta |= PK_PLANE; w[0] = dt(sub(mk(r + 2), F.c0), F.ax); w[1] = sg[s]; }
+            else if (shape == SH_CYL) { meta |= PK_CYL; w[0] = r[8]; w[1] = r[8] * r[8]; }
+            else if (shape == SH_SPHERE) { meta |= PK_SPHERE; const double t = dt(sub(mk(r + 2), F.c0), F.ax); w[0] = t; w[1] = r[5]; w[2] = t * t - r[5] * r[5]; }
+            else if (shape == SH_TORUS) { meta |= PK_TORUS; w[0] = dt(sub(mk(r + 2), F.c0), F.ax); w[1] = r[8]; w[2] = r[9]; w[3] = r[2]; w[4] = r[3]; w[5] = r[4]; }
+            else { meta |= PK_QUAD; double al, ga, pa, k0; revolution_form(F, r + 2, mk(r + 11), al, ga, pa, k0); w[0] = al; w[1] = ga; w[2] = pa; w[3] = k0 + r[14]; }
+            member_bounds(s, F, meta, w + 6);
+            put(meta, w, PREC - 1);
+        }
+    }
+    for (int s = 0; s < S; s++) if (fr[s] < 0) put((uint64_t)PK_GENERIC | ((uint64_t)(uint32_t)s << 4), nullptr, 0);
+    prog.resize(prog.size() + PREC, 0.0); // the kernel may prefetch one record past the end
 }
 
 // geometric normal of surface row at p, already multiplied by the orientation sign (what RayToX returns as

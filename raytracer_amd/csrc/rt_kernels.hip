@@ -66,6 +66,7 @@ struct KArgs {
     unsigned long long* prof; // RT_PROFILE builds: per-phase cycle sums (diagnostic only, never read by the kernel)
     // geometry
     const double* surf; int S; const double* recs; const uint32_t* smeta; const double* lut; int lut_prec;
+    const double* prog; int nprog; // frame program (rt_device.hpp find_hit)
     Prm P;
     int rows_lds;           // absorption_table rows kept in LDS (the rest goes straight to global atomics)
     int refill_min;         // refill when at least this many lanes of the wave are idle (or all are)
@@ -101,17 +102,17 @@ __device__ __forceinline__ void gen_point_ray(const KArgs& a, int64_t ray_id, V3
     r.s0 = 1; r.s1 = r.s2 = r.s3 = 0;
 }
 
+__device__ __forceinline__ void load_queue_ray(const KArgs& a, int64_t idx, RayState& q) {
+    const double* d = a.in_d; const int64_t st = a.in_stride;
+    q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
+    q.r.d = V3{ d[3 * st + idx], d[4 * st + idx], d[5 * st + idx] };
+    q.r.pol = V3{ d[6 * st + idx], d[7 * st + idx], d[8 * st + idx] };
+    q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
+    q.ray_id = a.in_i[idx]; q.parent = a.in_i[st + idx];
+    q.hash = (uint32_t)a.in_m[idx]; q.k = a.in_m[st + idx]; q.smix_last = a.in_m[2 * st + idx]; q.six_last = a.in_m[3 * st + idx]; q.flags = a.in_m[4 * st + idx];
+}
 __device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& q, bool wantfin) {
-    if (a.mode == 1) {
-        const double* d = a.in_d; const int64_t st = a.in_stride;
-        q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
-        q.r.d = V3{ d[3 * st + idx], d[4 * st + idx], d[5 * st + idx] };
-        q.r.pol = V3{ d[6 * st + idx], d[7 * st + idx], d[8 * st + idx] };
-        q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
-        q.ray_id = a.in_i[idx]; q.parent = a.in_i[st + idx];
-        q.hash = (uint32_t)a.in_m[idx]; q.k = a.in_m[st + idx]; q.smix_last = a.in_m[2 * st + idx]; q.six_last = a.in_m[3 * st + idx]; q.flags = a.in_m[4 * st + idx];
-        return;
-    }
+    if (a.mode == 1) { load_queue_ray(a, idx, q); return; }
     q.ray_id = a.ray_id_base + idx; q.parent = -1; q.hash = 0; q.k = 0; q.smix_last = 1; q.six_last = 0; q.flags = RF_PRIMARY; // RayTracer2.py:258-262
     if (a.mode == 2) gen_point_ray(a, q.ray_id, q.p, q.r);
     else {
@@ -155,9 +156,9 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* cou
 // Block-uniform arguments of the out-of-line nearest-hit search, at the start of dynamic LDS.  A non-kernel function
 // receives its arguments in vector registers, which would turn every geometry read into a per-lane load; read from
 // here and made scalar with readfirstlane they stay in SGPRs and the table reads stay scalar loads.
-struct LdsHdr { unsigned long long surf, recs, smeta; double min_travel; int S, compat, base, pad; };
+struct LdsHdr { unsigned long long surf, recs, smeta, prog; double min_travel; int S, compat, base, nprog; };
 constexpr int HDR_DOUBLES = 8;
-constexpr int TQ_DOUBLES = (BLOCK / 64) * TQ_SLOTS * 4; // per-wave torus queues, right behind the header
+constexpr int TQ_DOUBLES = (BLOCK / 64) * TQ_SLOTS * TQ_STRIDE; // per-wave torus queues, right behind the header
 static_assert(sizeof(LdsHdr) <= HDR_DOUBLES * 8, "LdsHdr");
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) { return ((unsigned long long)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
@@ -170,7 +171,8 @@ __device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last, bool act) {
     Geom G; Prm P;
     G.usurf = (udptr)uni64(H->surf); G.urec = (udptr)uni64(H->recs); G.smeta = (uuptr)uni64(H->smeta);
     G.surf = nullptr; G.lut = nullptr; G.lut_prec = 0; G.S = (int)uni32((uint32_t)H->S);
-    G.tq = smem + HDR_DOUBLES + (int)uni32(threadIdx.x / 64u) * (TQ_SLOTS * 4);
+    G.uprog = (udptr)uni64(H->prog); G.nprog = (int)uni32((uint32_t)H->nprog);
+    G.tq = smem + HDR_DOUBLES + (int)uni32(threadIdx.x / 64u) * (TQ_SLOTS * TQ_STRIDE);
     P.compat = (int)uni32((uint32_t)H->compat); P.base = (int)uni32((uint32_t)H->base);
     unsigned long long mt = uni64((unsigned long long)__double_as_longlong(H->min_travel));
     P.min_travel = __longlong_as_double((long long)mt);
@@ -200,14 +202,14 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(con
     if (threadIdx.x == 0) {
         LdsHdr* H = (LdsHdr*)smem;
         H->surf = (unsigned long long)a.surf; H->recs = (unsigned long long)a.recs; H->smeta = (unsigned long long)a.smeta;
-        H->min_travel = a.P.min_travel; H->S = a.S; H->compat = a.P.compat; H->base = a.P.base;
+        H->min_travel = a.P.min_travel; H->S = a.S; H->compat = a.P.compat; H->base = a.P.base; H->prog = (unsigned long long)a.prog; H->nprog = a.nprog;
     }
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
     for (int i = threadIdx.x; i < 2 * a.P.K; i += BLOCK) s_live[i] = 0u;
     __syncthreads();
 
-    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, smem + HDR_DOUBLES + (threadIdx.x / 64) * (TQ_SLOTS * 4) };
+    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, smem + HDR_DOUBLES + (threadIdx.x / 64) * (TQ_SLOTS * TQ_STRIDE), (udptr)a.prog, a.nprog };
     const Prm P = a.P;
     const int lane = lane_id();
     RayState q;
@@ -323,39 +325,53 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(con
 #ifndef RT_HIT_WAVES
 #define RT_HIT_WAVES 5
 #endif
-#ifndef RT_PHYS_WAVES
-#define RT_PHYS_WAVES 4
+#ifndef RT_HITF_WAVES
+#define RT_HITF_WAVES 6
 #endif
-__device__ __forceinline__ void load_pd(const KArgs& a, int64_t idx, V3& p, V3& d, int& six_last) {
-    if (a.mode == 1) {
-        const double* q = a.in_d; const int64_t st = a.in_stride;
-        p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
-        d = V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] };
-        six_last = a.in_m[3 * st + idx];
-        return;
-    }
-    six_last = 0;
-    if (a.mode == 2) { Ray10 r; gen_point_ray(a, a.ray_id_base + idx, p, r); d = r.d; }
-    else {
-        const double* q = a.in_d; const int64_t st = a.in_stride;
-        p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
-        V3 dir = V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] };
-        d = (1.0 / sqrt(dot(dir, dir))) * dir; // RayTracer2.py:221
-    }
+#ifndef RT_PHYS_WAVES
+#define RT_PHYS_WAVES 3
+#endif
+// what the nearest-hit kernel needs, and nothing else (kernel arguments live in SGPRs)
+struct HitArgs {
+    const double* in_d; const int32_t* in_m; int64_t in_stride, n_in;
+    const double* prog; int nprog; const double* recs; const double* surf; const uint32_t* smeta; int S;
+    double min_travel; int base, compat;
+    double* hit_l; int32_t* hit_so;
+};
+
+// initial rays (host layout as SoA, or generated point source) -> the ray queue both level kernels read
+template <int CF> __global__ void __launch_bounds__(BLOCK) k_level_init(const KArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= a.n_in) return;
+    const bool wantfin = (CF & FLAG_FINAL) && (a.P.flags & FLAG_FINAL);
+    RayState q; load_ray(a, idx, q, wantfin);
+    q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
+    store_ray(a.out, idx, q);
 }
 
-__global__ void __launch_bounds__(BLOCK, RT_HIT_WAVES) k_level_hit(const KArgs a) {
+// GENERIC: the program contains surfaces that fit no frame (see rt_device.hpp find_hit)
+template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HIT_WAVES : RT_HITF_WAVES) k_level_hit(const HitArgs a) {
     extern __shared__ double smem[]; // per-wave torus queues
-    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, nullptr, a.S, nullptr, 0, smem + (threadIdx.x / 64) * (TQ_SLOTS * 4) };
-    const Prm P = a.P;
-    const int64_t n = a.cnt_in ? (int64_t)*a.cnt_in : a.n_in;
+    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, nullptr, a.S, nullptr, 0, smem + (threadIdx.x / 64) * (TQ_SLOTS * TQ_STRIDE), (udptr)a.prog, a.nprog };
+    Prm P; P.K = 0; P.flags = 0; P.maxiter = 0; P.thrA = P.thrB = P.tir = 0; P.key0 = P.key1 = 0;
+    P.compat = a.compat; P.base = a.base; P.min_travel = a.min_travel;
+    const int64_t n = a.n_in, st = a.in_stride;
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     for (int64_t base = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); base < n; base += stride) { // wave-uniform trip count
         const int64_t idx = base + lane_id();
         const bool act = idx < n;
         V3 p = { 0, 0, 0 }, d = { 0, 0, 1 }; int six = 0;
-        if (act) { load_pd(a, idx, p, d, six); d = normalized_if(d); } // RayToShape.py:11-14
-        Hit h; find_hit(G, P, p, d, six, act, h);
+        if (act) {
+            const double* q = a.in_d;
+            p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
+            d = normalized_if(V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] }); // RayToShape.py:11-14
+            six = a.in_m[3 * st + idx];
+        }
+        Hit h;
+#ifdef RT_PROFILE
+        h.pm = h.ps = h.pc = h.pn = h.pf = h.pt_ = 0;
+#endif
+        find_hit<GENERIC>(G, P, p, d, six, act, h);
         if (act) { a.hit_l[idx] = h.l; a.hit_so[idx] = h.surf < 0 ? -1 : h.surf * 4 + h.orient + 1; }
     }
 }
@@ -371,7 +387,7 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr };
+    Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr, (udptr)a.prog, a.nprog };
     const Prm P = a.P;
     const bool full = (CF & FLAG_FULL) && (P.flags & FLAG_FULL), wantfin = (CF & FLAG_FINAL) && (P.flags & FLAG_FINAL);
     constexpr int BF = CF & FLAG_SINGLE;
@@ -382,7 +398,7 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
     for (int64_t base = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); base < n; base += stride) {
         const int64_t idx = base + lane_id();
         if (idx < n) {
-            RayState q; load_ray(a, idx, q, wantfin);
+            RayState q; load_queue_ray(a, idx, q);
             q.k = k;
             q.r.d = normalized_if(q.r.d);
             Hit h; h.l = a.hit_l[idx];
@@ -456,6 +472,8 @@ struct rt_ctx {
     std::string err;
     // geometry
     double* d_surf = nullptr; double* d_recs = nullptr; uint32_t* d_smeta = nullptr; double* d_lut = nullptr;
+    double* d_prog = nullptr; int nprog_frames = 0, nprog_generic = 0; // frame program, then the all-generic program
+    bool use_frames = true, frames_have_generic = false;
     bool has_rayleigh = false;
     int S = 0, n_atoms = 0, n_code = 0, lut_n = 0;
     // persistent small buffers
@@ -467,8 +485,11 @@ struct rt_ctx {
     std::vector<double> rec; std::vector<int32_t> rec_step, rec_flags; std::vector<int64_t> rec_ray, rec_parent;
     std::vector<double> fin;
     double kernel_ms = 0; int n_launches = 0;
+    double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
+    unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
-    size_t workspace_bytes = (size_t)8 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
+    size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
+    int level_steps = 16; int64_t level_min_rays = 1 << 17; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0;
 };
 
 static std::string g_init_err;
@@ -492,13 +513,18 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     const char* rf = getenv("RT_REFILL_MIN"); if (rf && atoi(rf) > 0) ctx->refill_min = atoi(rf);
     const char* bc = getenv("RT_BLOCKS_PER_CU"); if (bc && atoi(bc) > 0) ctx->blocks_per_cu = atoi(bc);
     const char* nc = getenv("RT_NODICE_CHUNK"); if (nc && atoll(nc) > 0) ctx->nodice_chunk = atoll(nc);
+    const char* nf = getenv("RT_NO_FRAMES"); if (nf && atoi(nf) > 0) ctx->use_frames = false;
+    const char* ls = getenv("RT_LEVEL_STEPS"); if (ls && atoi(ls) >= 0) ctx->level_steps = atoi(ls);
+    const char* lm = getenv("RT_LEVEL_MIN_RAYS"); if (lm && atoll(lm) >= 0) ctx->level_min_rays = atoll(lm);
+    const char* hb = getenv("RT_HIT_BLOCKS_PER_CU"); if (hb && atoi(hb) >= 0) ctx->hit_blocks_per_cu = atoi(hb);
+    const char* pb = getenv("RT_PHYS_BLOCKS_PER_CU"); if (pb && atoi(pb) >= 0) ctx->phys_blocks_per_cu = atoi(pb);
     *out = ctx; return 0;
 }
 
 extern "C" void rt_free(rt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps);
+    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps); hipFree(ctx->d_lvl);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -518,6 +544,11 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "blocks_per_cu") ctx->blocks_per_cu = (int)value;
     else if (k == "nodice_chunk") ctx->nodice_chunk = (int64_t)value;
     else if (k == "lds_budget_kb") ctx->lds_budget = (size_t)(value * 1024);
+    else if (k == "frames") ctx->use_frames = value != 0;
+    else if (k == "level_steps") ctx->level_steps = (int)value;
+    else if (k == "level_min_rays") ctx->level_min_rays = (int64_t)value;
+    else if (k == "hit_blocks_per_cu") ctx->hit_blocks_per_cu = (int)value;
+    else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
     else { ctx->err = "rt_set_option: unknown key " + k; return -1; }
     return 0;
 }
@@ -547,10 +578,24 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
         if (kind == 3) { int ax = (int)atoms[(size_t)i * ATOM + 3]; if (ax < 0 || ax > 2) { ctx->err = "rt_set_surfaces: bad coordinate atom"; return -1; } }
     }
     CK(hipSetDevice(ctx->device));
-    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta);
-    ctx->d_surf = ctx->d_recs = nullptr; ctx->d_smeta = nullptr;
-    std::vector<double> recs; std::vector<uint32_t> smeta;
+    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog);
+    ctx->d_surf = ctx->d_recs = ctx->d_prog = nullptr; ctx->d_smeta = nullptr;
+    std::vector<double> recs, prog, prog_generic; std::vector<uint32_t> smeta;
     build_device_tables(table, n_surf, atoms, n_atoms, code, recs, smeta);
+    build_program(table, n_surf, atoms, code, true, recs, smeta, prog);
+    build_program(table, n_surf, atoms, code, false, recs, smeta, prog_generic);
+    finish_device_tables(recs);
+    if (const char* sk = getenv("RT_DEBUG_SKIP_KINDS")) { // timing experiments only (results are wrong): drop program records by kind
+        const unsigned mask = (unsigned)atoi(sk); std::vector<double> kept;
+        for (size_t i = 0; i + PREC <= prog.size(); i += PREC) { uint64_t m; memcpy(&m, &prog[i], 8); if (i + PREC == prog.size() || !((mask >> (m & 15u)) & 1u)) kept.insert(kept.end(), prog.begin() + i, prog.begin() + i + PREC); }
+        prog.swap(kept);
+    }
+    ctx->frames_have_generic = false;
+    for (size_t i = 0; i + PREC < prog.size(); i += PREC) { uint64_t m; memcpy(&m, &prog[i], 8); if ((m & 15u) == PK_GENERIC) ctx->frames_have_generic = true; }
+    ctx->nprog_frames = (int)(prog.size() / PREC) - 1; ctx->nprog_generic = (int)(prog_generic.size() / PREC) - 1;
+    prog.insert(prog.end(), prog_generic.begin(), prog_generic.end());
+    CK(hipMalloc(&ctx->d_prog, sizeof(double) * prog.size()));
+    CK(hipMemcpy(ctx->d_prog, prog.data(), sizeof(double) * prog.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&ctx->d_surf, sizeof(double) * (size_t)n_surf * ROW));
     CK(hipMalloc(&ctx->d_recs, sizeof(double) * recs.size()));
     CK(hipMalloc(&ctx->d_smeta, 4 * smeta.size()));
@@ -602,6 +647,10 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     CK(hipMemsetAsync(ctx->d_table, 0, telems * 8, ctx->stream));
     CK(hipMemsetAsync(ctx->d_steps, 0, sizeof(unsigned long long) * 2 * (size_t)K, ctx->stream));
     ctx->K = K; ctx->n_rays = n; ctx->kernel_ms = 0; ctx->n_launches = 0;
+    for (int i = 0; i < 3; i++) { ctx->ms_kind[i] = 0; ctx->n_kind[i] = 0; }
+    // level-synchronous path: single-child runs with at most one child per ray and step
+    const bool level = single && ctx->level_steps > 0 && !(prm->follow_threshold[1] < 0);
+    if (level && ctx->lvl_K < K) { hipFree(ctx->d_lvl); ctx->d_lvl = nullptr; CK(hipMalloc(&ctx->d_lvl, sizeof(unsigned long long) * ((size_t)K + 2))); ctx->lvl_K = K; }
     ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
     ctx->fin.clear(); if (wantfin) ctx->fin.resize((size_t)n * FIN);
 
@@ -628,6 +677,11 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (mode == 0 && !d_soa) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (13 * 8 * 2))));
         if (wantfin) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (FIN * 8))));
         if (prm->follow_threshold[1] < 0) q_cap = chunk * K; // degenerate: reflected child followed as well
+        if (level) { // two ray queues (ping-pong) + the hit of every live ray
+            const size_t per_ray = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12;
+            chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / per_ray)));
+            q_cap = chunk;
+        }
     } else {
         chunk = std::min<int64_t>(n, ctx->nodice_chunk);
         q_cap = std::max<int64_t>(4 * chunk, 1 << 16);
@@ -635,6 +689,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     }
     if (full && rec_cap < chunk) { rec_cap = chunk; }
 
+    DevBuf b_hl, b_hso;
+    if (level) { CK(hipMalloc(&b_hl.p, 8 * (size_t)chunk)); CK(hipMalloc(&b_hso.p, 4 * (size_t)chunk)); }
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
     Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
     if (q_cap > 0) { if (alloc_queue(ctx, q[0], b_q0d, b_q0i, b_q0m, q_cap)) return -1; if (alloc_queue(ctx, q[1], b_q1d, b_q1i, b_q1m, q_cap)) return -1; }
@@ -648,6 +704,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     KArgs a; memset(&a, 0, sizeof a);
     a.surf = ctx->d_surf; a.S = S; a.recs = ctx->d_recs; a.smeta = ctx->d_smeta;
     a.lut = ctx->d_lut; a.lut_prec = ctx->lut_n > 0 ? ctx->lut_n - 1 : 1;
+    if (ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2)) { a.prog = ctx->d_prog; a.nprog = ctx->nprog_frames; }
+    else { a.prog = ctx->d_prog + (size_t)(ctx->nprog_frames + 1) * PREC; a.nprog = ctx->nprog_generic; }
     a.P.K = K; a.P.flags = prm->flags; a.P.compat = prm->compat; a.P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
     a.P.base = (prm->compat & RT_COMPAT_PY_INDEX) ? 0 : 1; a.P.min_travel = prm->min_travel_length; a.P.thrA = prm->follow_threshold[0]; a.P.thrB = prm->follow_threshold[1];
     a.P.tir = prm->tir_handling; a.P.key0 = (uint32_t)prm->seed; a.P.key1 = (uint32_t)(prm->seed >> 32);
@@ -656,8 +714,22 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     a.rec = (double*)b_rec.p; a.rec_cap = rec_cap; a.rec_step = (int32_t*)b_rstep.p; a.rec_ray = (int64_t*)b_rray.p; a.rec_parent = (int64_t*)b_rpar.p; a.rec_flags = (int32_t*)b_rflag.p;
     a.fin = (double*)b_fin.p; a.rows_lds = rows_lds; a.refill_min = ctx->refill_min;
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
+    a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
+    void (*kphys)(const KArgs) = out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : k_level_phys<FLAG_SINGLE>;
+    void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
+    const bool prog_generic = !(ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2)) || ctx->frames_have_generic;
+    void (*khit)(const HitArgs) = prog_generic ? k_level_hit<true> : k_level_hit<false>;
+    HitArgs ha; memset(&ha, 0, sizeof ha);
+    ha.prog = a.prog; ha.nprog = a.nprog; ha.recs = ctx->d_recs; ha.surf = ctx->d_surf; ha.smeta = ctx->d_smeta; ha.S = S;
+    ha.min_travel = a.P.min_travel; ha.base = a.P.base; ha.compat = a.P.compat; ha.hit_l = (double*)b_hl.p; ha.hit_so = (int32_t*)b_hso.p;
+    const size_t lds_hit = (size_t)TQ_DOUBLES * 8, lds_phys = (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 16;
+    if (level) {
+        if (lds_phys > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
+        CK(hipFuncSetAttribute((const void*)kphys, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
+    }
+    const int hit_bpc = ctx->hit_blocks_per_cu > 0 ? ctx->hit_blocks_per_cu : 4096, phys_bpc = ctx->phys_blocks_per_cu > 0 ? ctx->phys_blocks_per_cu : RT_PHYS_WAVES;
 
-    hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+    hipEvent_t ev0, ev1, ev2, ev3; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1)); CK(hipEventCreate(&ev2)); CK(hipEventCreate(&ev3));
     int rc = 0;
     for (int64_t off = 0; off < n && rc == 0; off += chunk) {
         int64_t m = std::min<int64_t>(chunk, n - off);
@@ -673,7 +745,44 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             }
         }
         int cur = 0;
-        for (int gen = 0; gen <= K; gen++) {
+        int64_t live = m; int k0 = 0;
+        if (level) {
+            CK(hipMemsetAsync(ctx->d_lvl, 0, sizeof(unsigned long long) * ((size_t)K + 2), ctx->stream));
+            if (K > 0 && ctx->level_steps > 0 && live >= ctx->level_min_rays) { // initial rays -> queue 1 (step 0 writes queue 0)
+                a.out = q[1];
+                hipLaunchKernelGGL(kinit, dim3((unsigned)((live + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, a);
+                CK(hipGetLastError());
+                a.mode = 1; a.in_d = q[1].d; a.in_i = q[1].i; a.in_m = q[1].m; a.in_stride = q[1].cap;
+            }
+            for (; k0 < K && k0 < ctx->level_steps && live > 0 && live >= ctx->level_min_rays; k0++) {
+                a.step = k0; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k0 + 1;
+                ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = a.in_stride; ha.n_in = live;
+                const int64_t nb = (live + BLOCK - 1) / BLOCK;
+                CK(hipEventRecord(ev0, ctx->stream));
+                hipLaunchKernelGGL(khit, dim3((unsigned)std::min<int64_t>(nb, (int64_t)ctx->n_cu * hit_bpc)), dim3(BLOCK), lds_hit, ctx->stream, ha);
+                CK(hipEventRecord(ev1, ctx->stream));
+                hipLaunchKernelGGL(kphys, dim3((unsigned)std::min<int64_t>(nb, (int64_t)ctx->n_cu * phys_bpc)), dim3(BLOCK), lds_phys, ctx->stream, a);
+                CK(hipEventRecord(ev2, ctx->stream));
+                CK(hipGetLastError());
+                unsigned long long nxt = 0, cnt[4];
+                CK(hipMemcpyAsync(&nxt, ctx->d_lvl + k0 + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipMemcpyAsync(cnt, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipStreamSynchronize(ctx->stream));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, ev0, ev1)); ctx->ms_kind[1] += ms; ctx->n_kind[1]++; ctx->kernel_ms += ms;
+                CK(hipEventElapsedTime(&ms, ev1, ev2)); ctx->ms_kind[2] += ms; ctx->n_kind[2]++; ctx->kernel_ms += ms;
+                ctx->n_launches += 2;
+                int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
+                if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace)" : "rt_trace: ray queue overflow"; rc = -3; break; }
+                live = (int64_t)nxt;
+                a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap;
+                cur ^= 1;
+            }
+            if (rc) break;
+            a.n_in = live; a.tail = ctx->d_counters + 1;
+        }
+        // persistent kernel: everything (ray-splitting runs, one launch per generation) or the tail of a level-synchronous run
+        for (int gen = 0; gen <= K && live > 0 && k0 < K; gen++) {
             a.out = q[cur];
             int64_t blocks = std::min<int64_t>((a.n_in + BLOCK - 1) / BLOCK, (int64_t)ctx->n_cu * bpc);
             CK(hipEventRecord(ev0, ctx->stream));
@@ -684,6 +793,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             CK(hipMemcpyAsync(cnt, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
             float ms = 0; CK(hipEventElapsedTime(&ms, ev0, ev1)); ctx->kernel_ms += ms; ctx->n_launches++;
+            ctx->ms_kind[0] += ms; ctx->n_kind[0]++;
             int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
             if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace or lower nodice_chunk)" : "rt_trace: ray queue overflow (lower nodice_chunk)"; rc = -3; break; }
             unsigned long long spawned = cnt[1];
@@ -713,7 +823,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         }
         if (wantfin) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));
     }
-    hipEventDestroy(ev0); hipEventDestroy(ev1);
+    hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(ev2); hipEventDestroy(ev3);
     if (rc) return rc;
     // ---- tallies and the reference's step bookkeeping (RayTracer2.py:266-270, 405-407, 542)
     ctx->table.assign(telems, 0.0); std::vector<unsigned long long> st(2 * (size_t)K);
@@ -780,5 +890,9 @@ extern "C" int rt_result_records(rt_ctx* ctx, double* rec, int32_t* step, int64_
 extern "C" int rt_result_final(rt_ctx* ctx, double* rows) {
     if (ctx->fin.empty()) { ctx->err = "rt_result_final: trace was run without RT_FLAG_FINAL_ROWS"; return -1; }
     memcpy(rows, ctx->fin.data(), ctx->fin.size() * 8); return 0;
+}
+extern "C" int rt_result_timing_by_kernel(rt_ctx* ctx, double ms[3], int32_t launches[3]) {
+    for (int i = 0; i < 3; i++) { if (ms) ms[i] = ctx->ms_kind[i]; if (launches) launches[i] = ctx->n_kind[i]; }
+    return 0;
 }
 extern "C" int rt_result_timing(rt_ctx* ctx, double* kernel_ms, int32_t* n_launches) { if (kernel_ms) *kernel_ms = ctx->kernel_ms; if (n_launches) *n_launches = ctx->n_launches; return 0; }

@@ -25,7 +25,11 @@ extern "C" int hs_trace(const double* sp, const double* rays, int64_t n, const d
     for (int si = 0; si < S; si++) { int off = (int)table[(size_t)si * ROW + 27], len = (int)table[(size_t)si * ROW + 28]; for (int i = off; i < off + len; i++) if ((code[i] >> 24) == 1) nA = std::max(nA, (int)(code[i] & 0xFFFFFFu) + 1); }
     std::vector<double> recs; std::vector<uint32_t> smeta;
     build_device_tables(table, S, atoms, nA, code, recs, smeta);
-    Geom G{ table, recs.data(), smeta.data(), table, S, lut, lut_n - 1, nullptr };
+    std::vector<double> prog;
+    const char* nf = getenv("RT_NO_FRAMES");
+    build_program(table, S, atoms, code, !(prm->compat & COMPAT_PY_ROOT2) && !(nf && atoi(nf) > 0), recs, smeta, prog);
+    finish_device_tables(recs);
+    Geom G{ table, recs.data(), smeta.data(), table, S, lut, lut_n - 1, nullptr, prog.data(), (int)(prog.size() / PREC) - 1 };
     Prm P; P.K = prm->max_scatters; P.flags = prm->flags; P.compat = prm->compat; P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
     P.base = (prm->compat & COMPAT_PY_INDEX) ? 0 : 1; P.min_travel = prm->min_travel_length; P.thrA = prm->follow_threshold[0]; P.thrB = prm->follow_threshold[1];
     P.tir = prm->tir_handling; P.key0 = (uint32_t)prm->seed; P.key1 = (uint32_t)(prm->seed >> 32);
@@ -75,3 +79,12 @@ extern "C" void hs_table(Result* r, double* dst) { memcpy(dst, r->table.data(), 
 extern "C" void hs_counts(Result* r, int64_t* live, int64_t* scat) { memcpy(live, r->live.data(), r->K * 8); memcpy(scat, r->scat.data(), r->K * 8); }
 extern "C" void hs_final(Result* r, double* dst) { if (!r->fin.empty()) memcpy(dst, r->fin.data(), r->fin.size() * 8); }
 extern "C" void hs_free(Result* r) { delete r; }
+// frame program of a geometry (test aid): copies up to cap records of PREC doubles, returns the record count
+extern "C" int hs_program(const double* table, int S, const double* atoms, const uint32_t* code, int frames_on, double* dst, int cap) {
+    std::vector<double> recs, prog; std::vector<uint32_t> smeta;
+    build_device_tables(table, S, atoms, 0, code, recs, smeta);
+    build_program(table, S, atoms, code, frames_on != 0, recs, smeta, prog);
+    int n = (int)(prog.size() / PREC) - 1;
+    for (int i = 0; i < n && i < cap; i++) memcpy(dst + (size_t)i * PREC, &prog[(size_t)i * PREC], PREC * 8);
+    return n;
+}
