@@ -559,7 +559,7 @@ constexpr int PREC = 16; // doubles per program record
 enum { PK_FRAME = 0, PK_PLANE = 1, PK_SPHERE = 2, PK_CYL = 3, PK_QUAD = 4, PK_GENERIC = 5, PK_TORUS = 6 };
 enum { FA_AXIAL = 0, FA_RADIAL2 = 1, FA_DIST2 = 2 };
 // record word 0 (64-bit integer): bits 0-3 kind, 4-15 surface number, 16-17 number of inline range atoms,
-// 20+4j..23+4j atom j: bits 0-1 coordinate (FA_*), 2 lower bound inclusive, 3 upper bound inclusive;
+// 20+4j..23+4j atom j: bits 0-1 coordinate (FA_*) (bounds are exclusive; inclusive ones are stored one ulp wider);
 // 32-51 first record / 52-63 number of records of the residual bounds program.
 // words 1-6: constants of the kind; words 7+3j..9+3j: atom j {lo, hi, t}.
 //   PK_FRAME c0(3) a^(3) | PK_PLANE ka, sigma | PK_CYL r, r^2 | PK_SPHERE t, r, t^2 - r^2 | PK_QUAD alpha, gamma, pa, R'
@@ -575,30 +575,32 @@ RT_HD double frame_coord(const FrameQ& F, uint32_t coord, double t, double l) {
 }
 // candidate tests without short-circuit evaluation: the operands are cheap and per lane, a branch per "&&" is not
 RT_HD bool wins_nb(double l_, double lmin, double bl, bool first) { return (l_ > lmin) & ((l_ < bl) | ((l_ == bl) & first)); }
-RT_HD bool in_range(double v, double lo, double hi, uint32_t am) { return ((am & 4u) ? (v >= lo) : (v > lo)) & ((am & 8u) ? (v <= hi) : (v < hi)); }
+// both bounds strict: build_program() moves an inclusive bound one ulp outwards (v >= lo <=> v > nextafter(lo, -inf))
+RT_HD bool in_range(double v, double lo, double hi) { return (v > lo) & (v < hi); }
 
 // Roots l0, l1 of frame member `R` (orientations o0, o1; ok0, ok1 = root exists and is not tangent): range atoms,
 // residual bounds, running minimum.
-RT_HD void frame_candidates(const Geom& G, const Prm& P, const FrameQ& F, const PRec& R, uint32_t mlo, uint32_t mhi, V3 sp, V3 d, int six_last, bool act,
+template <bool TWO> RT_HD void frame_candidates(const Geom& G, const Prm& P, const FrameQ& F, const PRec& R, uint32_t mlo, uint32_t mhi, V3 sp, V3 d, int six_last, bool act,
                             double l0, double l1, int o0, int o1, bool ok0, bool ok1, Hit& h) {
     const int n = (int)((mlo >> 4) & 0xFFFu);
     const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
     const bool first = n < h.surf;
-    bool c0_ = act & ok0 & wins_nb(l0, lmin, h.l, first), c1_ = act & ok1 & wins_nb(l1, lmin, h.l, first);
+    bool c0_ = act & ok0 & wins_nb(l0, lmin, h.l, first), c1_ = TWO ? (act & ok1 & wins_nb(l1, lmin, h.l, first)) : false;
     const uint32_t na = (mlo >> 16) & 3u;
-    if (na > 0) { const uint32_t am = (mlo >> 20) & 15u; c0_ = c0_ & in_range(frame_coord(F, am & 3u, R.w[9], l0), R.w[7], R.w[8], am); c1_ = c1_ & in_range(frame_coord(F, am & 3u, R.w[9], l1), R.w[7], R.w[8], am); }
-    if (na > 1) { const uint32_t am = (mlo >> 24) & 15u; c0_ = c0_ & in_range(frame_coord(F, am & 3u, R.w[12], l0), R.w[10], R.w[11], am); c1_ = c1_ & in_range(frame_coord(F, am & 3u, R.w[12], l1), R.w[10], R.w[11], am); }
-    if (na > 2) { const uint32_t am = (mlo >> 28) & 15u; c0_ = c0_ & in_range(frame_coord(F, am & 3u, R.w[15], l0), R.w[13], R.w[14], am); c1_ = c1_ & in_range(frame_coord(F, am & 3u, R.w[15], l1), R.w[13], R.w[14], am); }
+    if (na > 0) { const uint32_t ck = (mlo >> 20) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, R.w[9], l0), R.w[7], R.w[8]); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, R.w[9], l1), R.w[7], R.w[8]); }
+    if (na > 1) { const uint32_t ck = (mlo >> 24) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, R.w[12], l0), R.w[10], R.w[11]); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, R.w[12], l1), R.w[10], R.w[11]); }
+    if (na > 2) { const uint32_t ck = (mlo >> 28) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, R.w[15], l0), R.w[13], R.w[14]); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, R.w[15], l1), R.w[13], R.w[14]); }
     const int blen = (int)(mhi >> 20);
     if (blen != 0) { // residual bounds program, at the point
         const int boff = (int)(mhi & 0xFFFFFu);
         if (RT_ANY(c0_)) { if (c0_) c0_ = inbounds(G, brec_load(G.urec + (size_t)boff * BREC), boff, blen, sp + l0 * d); }
-        if (RT_ANY(c1_)) { if (c1_) c1_ = inbounds(G, brec_load(G.urec + (size_t)boff * BREC), boff, blen, sp + l1 * d); }
+        if (TWO) { if (RT_ANY(c1_)) { if (c1_) c1_ = inbounds(G, brec_load(G.urec + (size_t)boff * BREC), boff, blen, sp + l1 * d); } }
     }
-    // same surface: the first smallest root (RayTracer2.py:319-321)
-    const bool take1 = c1_ & (!c0_ | (l1 < l0)), any = c0_ | c1_;
-    const double ln = take1 ? l1 : l0; const int on = take1 ? o1 : o0;
-    h.l = any ? ln : h.l; h.surf = any ? n : h.surf; h.orient = any ? on : h.orient;
+    if (TWO) { // same surface: the first smallest root (RayTracer2.py:319-321)
+        const bool take1 = c1_ & (!c0_ | (l1 < l0)), any = c0_ | c1_;
+        const double ln = take1 ? l1 : l0; const int on = take1 ? o1 : o0;
+        h.l = any ? ln : h.l; h.surf = any ? n : h.surf; h.orient = any ? on : h.orient;
+    } else { h.l = c0_ ? l0 : h.l; h.surf = c0_ ? n : h.surf; h.orient = c0_ ? o0 : h.orient; }
 }
 
 // Torus queue of frame members: slot = {p, q, r, t0} in, {l0..l3, sign bits of f'(l)} out (6 doubles per slot).
@@ -636,7 +638,7 @@ RT_HD void frame_torus_flush(const Geom& G, const Prm& P, const FrameQ& F, udptr
         for (int m = 0; m < 4; m += 2) {
             const uint32_t s0 = (uint32_t)(sg >> (2 * m)) & 3u, s1 = (uint32_t)(sg >> (2 * m + 2)) & 3u;
             const int o0 = -flip * (s0 == 1u ? 1 : -1), o1 = -flip * (s1 == 1u ? 1 : -1);
-            frame_candidates(G, P, F, R, mlo, mhi, sp, d, six_last, mine, q[m], q[m + 1], o0, o1, s0 != 0u, s1 != 0u, h);
+            frame_candidates<true>(G, P, F, R, mlo, mhi, sp, d, six_last, mine, q[m], q[m + 1], o0, o1, s0 != 0u, s1 != 0u, h);
         }
     }
     rt_wave_sync();
@@ -678,6 +680,8 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
         double l0 = NAN, l1 = NAN; int o0 = 0, o1 = 0; bool ok0 = false, ok1 = false;
         if (kind == PK_PLANE) {
             l0 = (R.w[1] - F.xa) * F.ida; o0 = -(int)R.w[2] * F.sda; ok0 = F.sda != 0;
+            frame_candidates<false>(G, P, F, R, mlo, mhi, sp, d, six_last, act, l0, l1, o0, o1, ok0, ok1, h);
+            continue;
         } else if (kind == PK_CYL) {
             const double rad = R.w[1], c = F.uu - R.w[2], disc = F.hb * F.hb - F.a * c;
             const double sq = rt_sqrt(disc);
@@ -737,7 +741,7 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
             }
             continue;
         }
-        frame_candidates(G, P, F, R, mlo, mhi, sp, d, six_last, act, l0, l1, o0, o1, ok0, ok1, h);
+        frame_candidates<true>(G, P, F, R, mlo, mhi, sp, d, six_last, act, l0, l1, o0, o1, ok0, ok1, h);
     }
     frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T);
     if (GENERIC) torus_flush(G, P, sp, d, six_last, act, h, TG);
@@ -859,8 +863,8 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
         }
         meta |= (uint64_t)rg.size() << 16;
         for (size_t j = 0; j < rg.size(); j++) {
-            meta |= (uint64_t)((uint32_t)rkind[j] | (rg[j].ilo ? 4u : 0u) | (rg[j].ihi ? 8u : 0u)) << (20 + 4 * j);
-            aw[3 * j] = rg[j].lo; aw[3 * j + 1] = rg[j].hi; aw[3 * j + 2] = rg[j].t;
+            meta |= (uint64_t)((uint32_t)rkind[j]) << (20 + 4 * j);
+            aw[3 * j] = rg[j].ilo ? nextafter(rg[j].lo, -INFINITY) : rg[j].lo; aw[3 * j + 1] = rg[j].ihi ? nextafter(rg[j].hi, INFINITY) : rg[j].hi; aw[3 * j + 2] = rg[j].t;
         }
         if (!rest.empty()) {
             std::vector<uint32_t> c2;
