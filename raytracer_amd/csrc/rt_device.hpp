@@ -1229,6 +1229,109 @@ template <int CF = -1> RT_HD void bounce_phys(const Geom& G, const Prm& P, RaySt
     b.fa = b.refr.s0 > P.thrA; b.fb = b.refl.s0 > P.thrB; // :518-519
 }
 
+// ---------------------------------------------------------------------------------------------- single-child step, tallies only
+// The same step as bounce_phys<FLAG_SINGLE>() for runs that keep neither records nor final rows: the dice of
+// python/RayTracer2.py:458-467 needs only the two children's intensities, so they are computed first and only the
+// surviving child is built.  Fewer live values (one child instead of three Ray10) is what lets the level kernel
+// run without register spills.
+struct LeanBounce {
+    int scat, surf_sc, smix_next, six_next, fa;
+    double bulk_abs, surf_abs, inc_intensity, s0_child; // s0_child: refracted_rays[:,6] after the dice
+    V3 p; Ray10 child;
+};
+RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b) {
+    Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
+    b.inc_intensity = q.r.s0;
+    b.scat = 0; b.surf_sc = 0; b.fa = 0; b.smix_next = 0; b.six_next = 0; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = 0;
+    if (h.surf < 0) return; // RayTracer2.py:404
+    const double* row = G.surf + h.surf * ROW;
+    const int st = (int)row[1];
+    const bool in = h.orient < 0; // RayTracer2.py:351-358
+    const double n1 = in ? row[16] : row[15], n2 = in ? row[15] : row[16], absl1 = in ? row[19] : row[18], rayl1 = in ? row[21] : row[20];
+    V3 pn = q.p + h.l * q.r.d;
+    const V3 nmech = surface_normal(row, pn, q.r.d, h.orient);
+    V3 sopt = sel(st == ST_RETRO, -q.r.d, nmech); // RayTracer2.m:332-333
+    b.smix_next = b.six_next = (h.surf + P.base) * h.orient; // RayTracer2.py:371
+    if (st == ST_DIFFUSE) { // RayTracer2.m:394-415
+        double ct = sqrt(rng_uniform(g)), stt = sqrt(1 - ct * ct), ph = rng_uniform(g) * TWO_PI, sph, cph;
+        sincos(ph, &sph, &cph);
+        V3 xt = cross(sopt, V3{ 1, 0, 0 }), yt = cross(sopt, V3{ 0, 1, 0 });
+        if (xt.x == 0 && xt.y == 0 && xt.z == 0) xt = yt;
+        xt = (1.0 / sqrt(dot(xt, xt))) * xt;
+        yt = cross(sopt, xt);
+        V3 od = ct * sopt + (stt * cph) * xt + (stt * sph) * yt - q.r.d;
+        sopt = (1.0 / sqrt(dot(od, od))) * od;
+    }
+    b.scat = 1;
+    double l_bulk = INFINITY;
+    if (rayl1 < INFINITY) l_bulk = -rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
+    const bool surf_sc = h.l <= l_bulk;
+    b.surf_sc = surf_sc;
+    const bool uni_sc = surf_sc && st == ST_UNIFIED, nor_sc = surf_sc && !uni_sc;
+    double l = h.l;
+    if (!surf_sc) { b.six_next = 0; l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
+    b.p = pn;
+    const double trans = exp(-l / absl1); // :424-427
+    b.bulk_abs = b.inc_intensity * (1 - trans);
+    Ray10 inc = q.r; inc.s0 *= trans; inc.s1 *= trans; inc.s2 *= trans; inc.s3 *= trans;
+    const double f = surf_sc ? 1 - row[17] : 1.0; // :447-449
+    // the child that survives the dice, before the rescaling: chosen; its intensity and the sum of both
+    Ray10 ch = inc; ch.s0 = ch.s1 = ch.s2 = ch.s3 = 0;
+    double tot = 0;
+    if (nor_sc) { // :438-439
+        FresnelCore c; fresnel_core(inc, sopt, n1, n2, c);
+        V3 ny; const bool goodcut = fresnel_yaxis(c, ny);
+        const double hs = 0.5 * (c.s0 + c.s1), hp = 0.5 * (c.s0 - c.s1);
+        const bool tirc = goodcut && c.sin_t >= 1 && P.tir >= 0; // RefractionReflectionAtInterface.m:221-225
+        double r_s0 = c.goodhit ? hs * c.Rs + hp * c.Rp : 0.0, t_s0 = c.goodhit ? hs * c.Ts + hp * c.Tp : c.s0;
+        if (tirc) t_s0 = r_s0 * P.tir;
+        r_s0 *= f; t_s0 *= f;
+        tot = r_s0 + t_s0;
+        const bool roll = rng_uniform(g) < (r_s0 / tot); // :458-462
+        // reflected child, or the refracted one where it is a copy of the reflected (tir_handling >= 0)
+        const bool as_refl = roll || tirc;
+        ch.pol = c.pol;
+        if (as_refl) {
+            ch.d = goodcut ? c.cos_i * c.n - c.sin_i * ny : -c.d;
+            const double k = roll ? 1.0 : P.tir;
+            if (c.goodhit) { ch.s0 = (hs * c.Rs + hp * c.Rp) * k; ch.s1 = (hs * c.Rs - hp * c.Rp) * k; ch.s2 = (c.s2 * c.cr - c.s3 * c.ci) * k; ch.s3 = (c.s2 * c.ci + c.s3 * c.cr) * k; }
+        } else {
+            ch.d = c.d; ch.s0 = c.s0; ch.s1 = c.s1; ch.s2 = c.s2; ch.s3 = c.s3;
+            if (c.goodhit) { ch.s0 = hs * c.Ts + hp * c.Tp; ch.s1 = hs * c.Ts - hp * c.Tp; ch.s2 = c.s2 * c.tst; ch.s3 = c.s3 * c.tst; }
+            if (goodcut) ch.d = (c.sin_t >= 1) ? -ny : (-c.cos_t) * c.n - c.sin_t * ny;
+        }
+        ch.s0 *= f; ch.s1 *= f; ch.s2 *= f; ch.s3 *= f;
+    } else {
+        Ray10 r;
+        if (uni_sc) { // :443-444
+            const double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
+            UnifiedOut u = unified(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
+            r = u.r; rng_align(g, u.idx);
+            r.s0 *= f; r.s1 *= f; r.s2 *= f; r.s3 *= f;
+        } else r = rayleigh(g, inc, G.lut, G.lut_prec); // :452-454
+        tot = r.s0 + 0.0;
+        const bool roll = rng_uniform(g) < (r.s0 / tot);
+        if (roll) ch = r;
+    }
+    double resc = tot / ch.s0; // :463-466
+    if (isnan(resc)) resc = 0;
+    if (isnan(tot)) tot = 0;
+    ch.s0 = tot; ch.s1 *= resc; ch.s2 *= resc; ch.s3 *= resc;
+    b.child = ch; b.s0_child = tot;
+    b.surf_abs = inc.s0 - tot; // :471
+    b.fa = tot > P.thrA; // :518
+}
+RT_HD RayState lean_child(const RayState& q, const LeanBounce& b) { // child_of(q, b, false, true)
+    RayState c;
+    c.p = b.p; c.r = b.child;
+    c.ray_id = q.ray_id; c.parent = -1; c.k = q.k + 1;
+    c.hash = path_hash(q.hash, q.k, 0);
+    c.smix_last = -b.smix_next;
+    c.six_last = b.six_next < 0 ? -b.six_next : b.six_next;
+    c.flags = q.flags;
+    return c;
+}
+
 template <int CF = -1> RT_HD void bounce(const Geom& G, const Prm& P, RayState& q, Bounce& b) {
     Hit h; bounce_hit(G, P, q, true, h); bounce_phys<CF>(G, P, q, h, b);
 }

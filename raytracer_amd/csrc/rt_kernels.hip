@@ -74,6 +74,10 @@ struct KArgs {
     int step;                               // the step k both kernels work on
     const unsigned long long* cnt_in;       // number of live rays of this step (null: n_in)
     double* hit_l; int32_t* hit_so;         // nearest hit of live ray i: distance, surface * 4 + orientation + 1 (-1: none)
+    // segments: block b of a level kernel owns queue slots [b * seg_cap, b * seg_cap + seg_in[b]) and writes the children
+    // of its rays, compacted, into the same range of the output queue (count -> seg_out[b]).  No counter is shared
+    // between blocks: one atomic on one address per wave and step was what the physics kernel spent most of its time on.
+    const uint32_t* seg_in; uint32_t* seg_out; int64_t seg_cap;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -151,6 +155,16 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* cou
     unsigned int lo = __shfl((unsigned int)base, leader), hi = __shfl((unsigned int)(base >> 32), leader);
     base = ((unsigned long long)hi << 32) | lo;
     return base + (unsigned long long)__popcll(act & ((1ull << lane) - 1ull));
+}
+
+// the same from a counter in LDS
+__device__ __forceinline__ uint32_t wave_alloc_lds(uint32_t* counter) {
+    unsigned long long act = __ballot(1);
+    int lane = lane_id(), leader = __ffsll((long long)act) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(act));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
 }
 
 // Block-uniform arguments of the out-of-line nearest-hit search, at the start of dynamic LDS.  A non-kernel function
@@ -337,6 +351,7 @@ struct HitArgs {
     const double* prog; int nprog; const double* recs; const double* surf; const uint32_t* smeta; int S;
     double min_travel; int base, compat;
     double* hit_l; int32_t* hit_so;
+    const uint32_t* seg_in; int64_t seg_cap; int split; // split blocks share one segment
 };
 
 // initial rays (host layout as SoA, or generated point source) -> the ray queue both level kernels read
@@ -347,6 +362,17 @@ template <int CF> __global__ void __launch_bounds__(BLOCK) k_level_init(const KA
     RayState q; load_ray(a, idx, q, wantfin);
     q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
     store_ray(a.out, idx, q);
+    if (idx % a.seg_cap == 0) a.seg_out[idx / a.seg_cap] = (uint32_t)(a.n_in - idx < a.seg_cap ? a.n_in - idx : a.seg_cap);
+}
+// segments -> dense queue (hand-over to the persistent kernel)
+__global__ void __launch_bounds__(BLOCK) k_level_compact(const KArgs a) {
+    __shared__ unsigned long long s_base;
+    const int64_t n = a.seg_in[blockIdx.x], base = (int64_t)blockIdx.x * a.seg_cap;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(a.tail, (unsigned long long)n);
+    __syncthreads();
+    const int64_t ob = (int64_t)s_base;
+    for (int64_t i = threadIdx.x; i < n; i += BLOCK) { RayState q; load_queue_ray(a, base + i, q); store_ray(a.out, ob + i, q); }
 }
 
 // GENERIC: the program contains surfaces that fit no frame (see rt_device.hpp find_hit)
@@ -355,9 +381,9 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
     Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, nullptr, a.S, nullptr, 0, smem + (threadIdx.x / 64) * (TQ_SLOTS * TQ_STRIDE), (udptr)a.prog, a.nprog };
     Prm P; P.K = 0; P.flags = 0; P.maxiter = 0; P.thrA = P.thrB = P.tir = 0; P.key0 = P.key1 = 0;
     P.compat = a.compat; P.base = a.base; P.min_travel = a.min_travel;
-    const int64_t n = a.n_in, st = a.in_stride;
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t base = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); base < n; base += stride) { // wave-uniform trip count
+    const int sg = (int)blockIdx.x / a.split, part = (int)blockIdx.x % a.split;
+    const int64_t st = a.in_stride, seg0 = (int64_t)sg * a.seg_cap, n = seg0 + (int64_t)a.seg_in[sg];
+    for (int64_t base = seg0 + (int64_t)part * BLOCK + (threadIdx.x & ~63); base < n; base += (int64_t)a.split * BLOCK) { // wave-uniform trip count
         const int64_t idx = base + lane_id();
         const bool act = idx < n;
         V3 p = { 0, 0, 0 }, d = { 0, 0, 1 }; int six = 0;
@@ -385,7 +411,7 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
     uint32_t* s_cnt = (uint32_t*)(s_tab + ntab);
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0u; // live, scattered, children
     __syncthreads();
     Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr, (udptr)a.prog, a.nprog };
     const Prm P = a.P;
@@ -393,9 +419,8 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
     constexpr int BF = CF & FLAG_SINGLE;
     const int k = a.step;
     KArgs t = a; t.rows_lds = 1; // tally_add(): row 0 of the LDS image is step k
-    const int64_t n = a.cnt_in ? (int64_t)*a.cnt_in : a.n_in;
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t base = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); base < n; base += stride) {
+    const int64_t seg0 = (int64_t)blockIdx.x * a.seg_cap, n = seg0 + (int64_t)a.seg_in[blockIdx.x];
+    for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
         const int64_t idx = base + lane_id();
         if (idx < n) {
             RayState q; load_queue_ray(a, idx, q);
@@ -404,32 +429,46 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
             Hit h; h.l = a.hit_l[idx];
             const int so = a.hit_so[idx];
             h.surf = so < 0 ? -1 : (so >> 2); h.orient = so < 0 ? 0 : (so & 3) - 1;
-            Bounce b; b.scat = 0;
-            bounce_phys<BF>(G, P, q, h, b);
             atomicAdd(&s_cnt[0], 1u);
-            if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
-            else {
-                atomicAdd(&s_cnt[1], 1u);
-                if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);
-                tally_add(t, s_tab, 0, 1, b.smix_next, b.bulk_abs);
-                tally_add(t, s_tab, 0, 3, b.smix_next, (b.fa ? 0.0 : b.refr.s0) + (b.fb ? 0.0 : b.refl.s0));
-                tally_add(t, s_tab, 0, 4, b.smix_next, (b.fa ? b.refr.s0 : 0.0) + (b.fb ? b.refl.s0 : 0.0));
-                int64_t myslot = -1;
-                if (full) {
-                    unsigned long long slot = wave_alloc(a.rec_count);
-                    if (slot < (unsigned long long)a.rec_cap) {
-                        fill_record(q, b, P, a.rec + slot, (size_t)a.rec_cap);
-                        a.rec_step[slot] = k; a.rec_ray[slot] = q.ray_id; a.rec_parent[slot] = q.parent; a.rec_flags[slot] = q.flags;
-                        myslot = (int64_t)slot;
-                    } else *a.overflow = 1;
+            if constexpr (CF == FLAG_SINGLE) { // tallies only: one child, built after the dice
+                LeanBounce b;
+                bounce_phys_single(G, P, q, h, b);
+                if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
+                else {
+                    atomicAdd(&s_cnt[1], 1u);
+                    if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);
+                    tally_add(t, s_tab, 0, 1, b.smix_next, b.bulk_abs);
+                    tally_add(t, s_tab, 0, b.fa ? 4 : 3, b.smix_next, b.s0_child);
+                    if (k + 1 < P.K && b.fa) {
+                        RayState c = lean_child(q, b);
+                        store_ray(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c); // at most one child per ray: the segment cannot overflow
+                    }
                 }
-                if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + (q.ray_id - a.slot_base) * FIN);
-                if (k + 1 < P.K && (b.fa || b.fb)) { // single child: exactly one of fa, fb can be set
-                    RayState c = child_of(q, b, !b.fa, b.fa != 0);
-                    c.parent = myslot;
-                    unsigned long long slot = wave_alloc(a.tail);
-                    if (slot < (unsigned long long)a.out.cap) store_ray(a.out, (int64_t)slot, c);
-                    else *a.overflow = 2;
+            } else {
+                Bounce b; b.scat = 0;
+                bounce_phys<BF>(G, P, q, h, b);
+                if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
+                else {
+                    atomicAdd(&s_cnt[1], 1u);
+                    if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);
+                    tally_add(t, s_tab, 0, 1, b.smix_next, b.bulk_abs);
+                    tally_add(t, s_tab, 0, 3, b.smix_next, (b.fa ? 0.0 : b.refr.s0) + (b.fb ? 0.0 : b.refl.s0));
+                    tally_add(t, s_tab, 0, 4, b.smix_next, (b.fa ? b.refr.s0 : 0.0) + (b.fb ? b.refl.s0 : 0.0));
+                    int64_t myslot = -1;
+                    if (full) {
+                        unsigned long long slot = wave_alloc(a.rec_count);
+                        if (slot < (unsigned long long)a.rec_cap) {
+                            fill_record(q, b, P, a.rec + slot, (size_t)a.rec_cap);
+                            a.rec_step[slot] = k; a.rec_ray[slot] = q.ray_id; a.rec_parent[slot] = q.parent; a.rec_flags[slot] = q.flags;
+                            myslot = (int64_t)slot;
+                        } else *a.overflow = 1;
+                    }
+                    if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + (q.ray_id - a.slot_base) * FIN);
+                    if (k + 1 < P.K && (b.fa || b.fb)) { // single child: exactly one of fa, fb can be set
+                        RayState c = child_of(q, b, !b.fa, b.fa != 0);
+                        c.parent = myslot;
+                        store_ray(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c);
+                    }
                 }
             }
         }
@@ -440,6 +479,8 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
     if (threadIdx.x == 0) {
         if (s_cnt[0]) atomicAdd(&a.n_live[k], (unsigned long long)s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&a.n_scat[k], (unsigned long long)s_cnt[1]);
+        a.seg_out[blockIdx.x] = s_cnt[2];
+        if (s_cnt[2]) atomicAdd(a.tail, (unsigned long long)s_cnt[2]);
     }
 }
 
@@ -489,7 +530,7 @@ struct rt_ctx {
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 16; int64_t level_min_rays = 1 << 17; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0;
+    int level_steps = 16; int64_t level_min_rays = 1 << 17; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 16;
 };
 
 static std::string g_init_err;
@@ -516,6 +557,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     const char* nf = getenv("RT_NO_FRAMES"); if (nf && atoi(nf) > 0) ctx->use_frames = false;
     const char* ls = getenv("RT_LEVEL_STEPS"); if (ls && atoi(ls) >= 0) ctx->level_steps = atoi(ls);
     const char* lm = getenv("RT_LEVEL_MIN_RAYS"); if (lm && atoll(lm) >= 0) ctx->level_min_rays = atoll(lm);
+    const char* hs = getenv("RT_HIT_SPLIT"); if (hs && atoi(hs) > 0) ctx->hit_split = atoi(hs);
     const char* hb = getenv("RT_HIT_BLOCKS_PER_CU"); if (hb && atoi(hb) >= 0) ctx->hit_blocks_per_cu = atoi(hb);
     const char* pb = getenv("RT_PHYS_BLOCKS_PER_CU"); if (pb && atoi(pb) >= 0) ctx->phys_blocks_per_cu = atoi(pb);
     *out = ctx; return 0;
@@ -548,6 +590,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "level_steps") ctx->level_steps = (int)value;
     else if (k == "level_min_rays") ctx->level_min_rays = (int64_t)value;
     else if (k == "hit_blocks_per_cu") ctx->hit_blocks_per_cu = (int)value;
+    else if (k == "hit_split") ctx->hit_split = (int)value;
     else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
     else { ctx->err = "rt_set_option: unknown key " + k; return -1; }
     return 0;
@@ -680,7 +723,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (level) { // two ray queues (ping-pong) + the hit of every live ray
             const size_t per_ray = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12;
             chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / per_ray)));
-            q_cap = chunk;
+            q_cap = chunk + (int64_t)ctx->n_cu * 8; // segments round the capacity up
         }
     } else {
         chunk = std::min<int64_t>(n, ctx->nodice_chunk);
@@ -689,8 +732,9 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     }
     if (full && rec_cap < chunk) { rec_cap = chunk; }
 
-    DevBuf b_hl, b_hso;
-    if (level) { CK(hipMalloc(&b_hl.p, 8 * (size_t)chunk)); CK(hipMalloc(&b_hso.p, 4 * (size_t)chunk)); }
+    DevBuf b_hl, b_hso, b_seg;
+    const int nseg_max = ctx->n_cu * 8;
+    if (level) { CK(hipMalloc(&b_hl.p, 8 * (size_t)q_cap)); CK(hipMalloc(&b_hso.p, 4 * (size_t)q_cap)); CK(hipMalloc(&b_seg.p, sizeof(uint32_t) * 2 * (size_t)nseg_max)); }
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
     Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
     if (q_cap > 0) { if (alloc_queue(ctx, q[0], b_q0d, b_q0i, b_q0m, q_cap)) return -1; if (alloc_queue(ctx, q[1], b_q1d, b_q1i, b_q1m, q_cap)) return -1; }
@@ -747,21 +791,30 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         int cur = 0;
         int64_t live = m; int k0 = 0;
         if (level) {
+            // segments: nseg blocks, each owns seg_cap consecutive queue slots through all level steps
+            const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * 8, (m + 4095) / 4096));
+            const int64_t seg_cap = (m + nseg - 1) / nseg;
+            uint32_t* seg[2] = { (uint32_t*)b_seg.p, (uint32_t*)b_seg.p + nseg_max };
             CK(hipMemsetAsync(ctx->d_lvl, 0, sizeof(unsigned long long) * ((size_t)K + 2), ctx->stream));
-            if (K > 0 && ctx->level_steps > 0 && live >= ctx->level_min_rays) { // initial rays -> queue 1 (step 0 writes queue 0)
-                a.out = q[1];
+            CK(hipMemsetAsync(b_seg.p, 0, sizeof(uint32_t) * 2 * (size_t)nseg_max, ctx->stream));
+            a.seg_cap = seg_cap; ha.seg_cap = seg_cap;
+            const bool go = K > 0 && ctx->level_steps > 0 && live >= ctx->level_min_rays;
+            if (go) { // initial rays -> queue 1 (step 0 writes queue 0)
+                a.out = q[1]; a.seg_out = seg[1];
                 hipLaunchKernelGGL(kinit, dim3((unsigned)((live + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, a);
                 CK(hipGetLastError());
                 a.mode = 1; a.in_d = q[1].d; a.in_i = q[1].i; a.in_m = q[1].m; a.in_stride = q[1].cap;
             }
+            int sin = 1; // seg[sin]: counts of the input queue
             for (; k0 < K && k0 < ctx->level_steps && live > 0 && live >= ctx->level_min_rays; k0++) {
                 a.step = k0; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k0 + 1;
-                ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = a.in_stride; ha.n_in = live;
-                const int64_t nb = (live + BLOCK - 1) / BLOCK;
+                a.seg_in = seg[sin]; a.seg_out = seg[sin ^ 1];
+                ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = a.in_stride; ha.n_in = live; ha.seg_in = seg[sin];
                 CK(hipEventRecord(ev0, ctx->stream));
-                hipLaunchKernelGGL(khit, dim3((unsigned)std::min<int64_t>(nb, (int64_t)ctx->n_cu * hit_bpc)), dim3(BLOCK), lds_hit, ctx->stream, ha);
+                ha.split = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->hit_split, (live / nseg + BLOCK - 1) / BLOCK));
+                hipLaunchKernelGGL(khit, dim3((unsigned)(nseg * ha.split)), dim3(BLOCK), lds_hit, ctx->stream, ha);
                 CK(hipEventRecord(ev1, ctx->stream));
-                hipLaunchKernelGGL(kphys, dim3((unsigned)std::min<int64_t>(nb, (int64_t)ctx->n_cu * phys_bpc)), dim3(BLOCK), lds_phys, ctx->stream, a);
+                hipLaunchKernelGGL(kphys, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
                 CK(hipEventRecord(ev2, ctx->stream));
                 CK(hipGetLastError());
                 unsigned long long nxt = 0, cnt[4];
@@ -773,8 +826,17 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 CK(hipEventElapsedTime(&ms, ev1, ev2)); ctx->ms_kind[2] += ms; ctx->n_kind[2]++; ctx->kernel_ms += ms;
                 ctx->n_launches += 2;
                 int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
-                if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace)" : "rt_trace: ray queue overflow"; rc = -3; break; }
+                if (ovf) { ctx->err = "rt_trace: record buffer overflow (raise workspace)"; rc = -3; break; }
                 live = (int64_t)nxt;
+                a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap;
+                cur ^= 1; sin ^= 1;
+            }
+            if (rc) break;
+            if (go && live > 0 && k0 < K) { // hand-over: the persistent kernel reads a dense queue
+                a.seg_in = seg[sin]; a.out = q[cur]; a.tail = ctx->d_counters + 1;
+                hipLaunchKernelGGL(k_level_compact, dim3((unsigned)nseg), dim3(BLOCK), 0, ctx->stream, a);
+                CK(hipGetLastError());
+                CK(hipMemsetAsync(ctx->d_counters + 1, 0, 8, ctx->stream));
                 a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap;
                 cur ^= 1;
             }

@@ -51,7 +51,16 @@ extern "C" int hs_trace(const double* sp, const double* rays, int64_t n, const d
         size_t nl = cur.size(); R->live[k] = (int64_t)nl;
         std::vector<Bounce> B(nl);
         int64_t nsc = 0;
-        for (size_t i = 0; i < nl; i++) { bounce(G, P, cur[i], B[i]); nsc += B[i].scat; }
+        const bool lean = P.flags == FLAG_SINGLE && !getenv("HS_NO_LEAN"); // the level kernel's tally-only step (bounce_phys_single)
+        for (size_t i = 0; i < nl; i++) {
+            if (lean) {
+                RayState& q = cur[i]; Hit h; bounce_hit(G, P, q, true, h);
+                LeanBounce lb; bounce_phys_single(G, P, q, h, lb);
+                Bounce& b = B[i]; b.scat = lb.scat; b.surf_sc = lb.surf_sc; b.smix_next = lb.smix_next; b.six_next = lb.six_next; b.fa = lb.fa; b.fb = 0;
+                b.bulk_abs = lb.bulk_abs; b.surf_abs = lb.surf_abs; b.inc_intensity = lb.inc_intensity; b.p = lb.p; b.refr = lb.child; b.refl = lb.child; b.refl.s0 = 0;
+            } else bounce(G, P, cur[i], B[i]);
+            nsc += B[i].scat;
+        }
         R->scat[k] = nsc;
         std::vector<RayState> nxt;
         if (nsc > 0) {
