@@ -340,7 +340,7 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(con
 #define RT_HIT_WAVES 5
 #endif
 #ifndef RT_HITF_WAVES
-#define RT_HITF_WAVES 6
+#define RT_HITF_WAVES 5
 #endif
 #ifndef RT_PHYS_WAVES
 #define RT_PHYS_WAVES 3
@@ -525,6 +525,7 @@ struct rt_ctx {
     std::vector<double> table; std::vector<int64_t> n_live, n_scat;
     std::vector<double> rec; std::vector<int32_t> rec_step, rec_flags; std::vector<int64_t> rec_ray, rec_parent;
     std::vector<double> fin;
+    std::vector<std::pair<void*, size_t>> pool; // cached device buffers (see DevBuf)
     double kernel_ms = 0; int n_launches = 0;
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
@@ -567,6 +568,7 @@ extern "C" void rt_free(rt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps); hipFree(ctx->d_lvl);
+    for (auto& pb : ctx->pool) hipFree(pb.first);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -586,6 +588,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "blocks_per_cu") ctx->blocks_per_cu = (int)value;
     else if (k == "nodice_chunk") ctx->nodice_chunk = (int64_t)value;
     else if (k == "lds_budget_kb") ctx->lds_budget = (size_t)(value * 1024);
+    else if (k == "release_workspace") { hipSetDevice(ctx->device); for (auto& pb : ctx->pool) hipFree(pb.first); ctx->pool.clear(); }
     else if (k == "frames") ctx->use_frames = value != 0;
     else if (k == "level_steps") ctx->level_steps = (int)value;
     else if (k == "level_min_rays") ctx->level_min_rays = (int64_t)value;
@@ -662,11 +665,30 @@ extern "C" int rt_set_rayleigh_lut(rt_ctx* ctx, const double* lut, int32_t n) {
 
 namespace {
 
-struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) hipFree(p); } };
+// Device buffers of a trace come from a per-context pool and go back to it: hipMalloc/hipFree of the multi-GB ray
+// queues cost milliseconds per call.  The pool is emptied by rt_free() or rt_set_option("release_workspace", 1).
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0; rt_ctx* owner = nullptr;
+    ~DevBuf() { if (!p) return; if (owner) owner->pool.push_back({ p, bytes }); else hipFree(p); }
+};
+hipError_t dev_alloc(rt_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    size_t best = (size_t)-1; int bi = -1;
+    for (size_t i = 0; i < ctx->pool.size(); i++) if (ctx->pool[i].second >= bytes && ctx->pool[i].second < best) { best = ctx->pool[i].second; bi = (int)i; }
+    if (bi >= 0 && best <= 2 * bytes + (1u << 20)) { b.p = ctx->pool[bi].first; b.bytes = best; b.owner = ctx; ctx->pool.erase(ctx->pool.begin() + bi); return hipSuccess; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { // make room: drop what is cached and try again
+        for (auto& pb : ctx->pool) hipFree(pb.first);
+        ctx->pool.clear(); (void)hipGetLastError();
+        e = hipMalloc(&b.p, bytes);
+    }
+    if (e == hipSuccess) { b.bytes = bytes; b.owner = ctx; } else b.p = nullptr;
+    return e;
+}
 
 int alloc_queue(rt_ctx* ctx, Queue& q, DevBuf& bd, DevBuf& bi, DevBuf& bm, int64_t cap) {
     q.cap = cap;
-    CK(hipMalloc(&bd.p, sizeof(double) * QD * (size_t)cap)); CK(hipMalloc(&bi.p, sizeof(int64_t) * QI * (size_t)cap)); CK(hipMalloc(&bm.p, sizeof(int32_t) * QM * (size_t)cap));
+    CK(dev_alloc(ctx, bd, sizeof(double) * QD * (size_t)cap)); CK(dev_alloc(ctx, bi, sizeof(int64_t) * QI * (size_t)cap)); CK(dev_alloc(ctx, bm, sizeof(int32_t) * QM * (size_t)cap));
     q.d = (double*)bd.p; q.i = (int64_t*)bi.p; q.m = (int32_t*)bm.p;
     return 0;
 }
@@ -734,16 +756,16 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 
     DevBuf b_hl, b_hso, b_seg;
     const int nseg_max = ctx->n_cu * 8;
-    if (level) { CK(hipMalloc(&b_hl.p, 8 * (size_t)q_cap)); CK(hipMalloc(&b_hso.p, 4 * (size_t)q_cap)); CK(hipMalloc(&b_seg.p, sizeof(uint32_t) * 2 * (size_t)nseg_max)); }
+    if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 2 * (size_t)nseg_max)); }
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
     Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
     if (q_cap > 0) { if (alloc_queue(ctx, q[0], b_q0d, b_q0i, b_q0m, q_cap)) return -1; if (alloc_queue(ctx, q[1], b_q1d, b_q1i, b_q1m, q_cap)) return -1; }
-    if (mode == 0 && !d_soa) { CK(hipMalloc(&b_in.p, 13 * 8 * (size_t)chunk)); CK(hipMalloc(&b_hs.p, 3 * 8 * (size_t)chunk)); CK(hipMalloc(&b_hr.p, 10 * 8 * (size_t)chunk)); }
+    if (mode == 0 && !d_soa) { CK(dev_alloc(ctx, b_in, 13 * 8 * (size_t)chunk)); CK(dev_alloc(ctx, b_hs, 3 * 8 * (size_t)chunk)); CK(dev_alloc(ctx, b_hr, 10 * 8 * (size_t)chunk)); }
     if (full) {
-        CK(hipMalloc(&b_rec.p, (size_t)REC * 8 * (size_t)rec_cap)); CK(hipMalloc(&b_rstep.p, 4 * (size_t)rec_cap)); CK(hipMalloc(&b_rray.p, 8 * (size_t)rec_cap));
-        CK(hipMalloc(&b_rpar.p, 8 * (size_t)rec_cap)); CK(hipMalloc(&b_rflag.p, 4 * (size_t)rec_cap));
+        CK(dev_alloc(ctx, b_rec, (size_t)REC * 8 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rstep, 4 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rray, 8 * (size_t)rec_cap));
+        CK(dev_alloc(ctx, b_rpar, 8 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rflag, 4 * (size_t)rec_cap));
     }
-    if (wantfin) CK(hipMalloc(&b_fin.p, (size_t)FIN * 8 * (size_t)chunk));
+    if (wantfin) CK(dev_alloc(ctx, b_fin, (size_t)FIN * 8 * (size_t)chunk));
 
     KArgs a; memset(&a, 0, sizeof a);
     a.surf = ctx->d_surf; a.S = S; a.recs = ctx->d_recs; a.smeta = ctx->d_smeta;
@@ -871,7 +893,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             CK(hipMemcpy(&nrec, ctx->d_counters + 2, 8, hipMemcpyDeviceToHost));
             if (nrec) {
                 size_t base = ctx->rec_step.size();
-                DevBuf rows; CK(hipMalloc(&rows.p, (size_t)REC * 8 * nrec));
+                DevBuf rows; CK(dev_alloc(ctx, rows, (size_t)REC * 8 * nrec));
                 hipLaunchKernelGGL(k_rec_to_rows, dim3((unsigned)((nrec * REC + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_rec.p, rec_cap, (int64_t)nrec, (double*)rows.p);
                 ctx->rec.resize((base + nrec) * REC); ctx->rec_step.resize(base + nrec); ctx->rec_flags.resize(base + nrec); ctx->rec_ray.resize(base + nrec); ctx->rec_parent.resize(base + nrec);
                 CK(hipMemcpyAsync(ctx->rec.data() + base * REC, rows.p, (size_t)REC * 8 * nrec, hipMemcpyDeviceToHost, ctx->stream));
@@ -915,7 +937,7 @@ extern "C" int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_
 }
 extern "C" int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int64_t n, uint64_t seed, int64_t ray_id_base, double* start, double* rays) {
     CK(hipSetDevice(ctx->device));
-    DevBuf s, r; CK(hipMalloc(&s.p, 24 * (size_t)n)); CK(hipMalloc(&r.p, 80 * (size_t)n));
+    DevBuf s, r; CK(dev_alloc(ctx, s, 24 * (size_t)n)); CK(dev_alloc(ctx, r, 80 * (size_t)n));
     KArgs a; memset(&a, 0, sizeof a);
     a.P.key0 = (uint32_t)seed; a.P.key1 = (uint32_t)(seed >> 32); a.ray_id_base = ray_id_base; a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
     hipLaunchKernelGGL(k_gen_point, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, n, (double*)s.p, (double*)r.p);
