@@ -179,7 +179,7 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) { retu
 } // namespace
 namespace rt {
 #ifdef RT_OOL_FIND_HIT
-__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last, bool act) {
+template <bool GEN> __device__ __noinline__ Hit find_hit_ool_t(V3 sp, V3 d, int six_last, bool act) {
     extern __shared__ double smem[];
     const LdsHdr* H = (const LdsHdr*)smem;
     Geom G; Prm P;
@@ -195,9 +195,10 @@ __device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last, bool act) {
 #ifdef RT_PROFILE
     h.pm = h.ps = h.pc = h.pn = h.pf = h.pt_ = 0;
 #endif
-    find_hit(G, P, sp, d, six_last, act, h);
+    find_hit<GEN>(G, P, sp, d, six_last, act, h);
     return h;
 }
+__device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last, bool act) { return find_hit_ool_t<true>(sp, d, six_last, act); }
 #endif
 } // namespace rt
 namespace {
@@ -205,7 +206,8 @@ namespace {
 #define RT_WAVES 4
 #endif
 // CF: flag set this instance is compiled for (FLAG_SINGLE exact; FLAG_FULL/FLAG_FINAL = "may be requested", 0 = never)
-template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
+// LEAN: tally-only single-child step (bounce_phys_single); GEN: the program has surfaces outside every frame
+template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
     extern __shared__ double smem[];
     // LDS image: surface rows (per-lane gather of the winning surface) | tally rows | per-step counters
     double* s_surf = smem + HDR_DOUBLES + TQ_DOUBLES;
@@ -266,11 +268,29 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(con
         pt[5] += 1; pt[6] += __popcll(__ballot(alive));
 #endif
         Hit h; h.l = INFINITY; h.surf = -1; h.orient = 0;
-        bounce_hit(G, P, q, alive, h); // all lanes: idle ones still serve the wave's torus queue
+        if constexpr (GEN) bounce_hit(G, P, q, alive, h); // all lanes: idle ones still serve the wave's torus queue
+        else { q.r.d = normalized_if(q.r.d); h = find_hit_ool_t<false>(q.p, q.r.d, q.six_last, alive); }
 #ifdef RT_PROFILE
         pt[4] += h.ps; pt[7] += h.pm; pt[8] += h.pc; pt[9] += h.pn; pt[10] += h.pf; pt[11] += h.pt_;
 #endif
         PROF_ADD(1)
+        if constexpr (LEAN) {
+            if (alive) {
+                const int k = q.k;
+                LeanBounce b; bounce_phys_single(G, P, q, h, b);
+                atomicAdd(&s_live[k], 1u);
+                if (!b.scat) { tally_add(a, s_tab, k, 2, q.smix_last, b.inc_intensity); alive = false; } // escaped: RayTracer2.py:485-486
+                else {
+                    atomicAdd(&s_scat[k], 1u);
+                    if (b.surf_sc) tally_add(a, s_tab, k, 0, b.smix_next, b.surf_abs);
+                    tally_add(a, s_tab, k, 1, b.smix_next, b.bulk_abs);
+                    tally_add(a, s_tab, k, b.fa ? 4 : 3, b.smix_next, b.s0_child);
+                    if (k + 1 >= P.K || !b.fa) alive = false;
+                    else q = lean_child(q, b);
+                }
+            }
+            continue;
+        }
         Bounce b; b.scat = 0;
         if (alive) bounce_phys<BF>(G, P, q, h, b);
         PROF_ADD(2)
@@ -531,7 +551,7 @@ struct rt_ctx {
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 16; int64_t level_min_rays = 1 << 17; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 16;
+    int level_steps = 24; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 16;
 };
 
 static std::string g_init_err;
@@ -730,6 +750,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     // kernel instance: exact on single-child; records/final rows compiled in only when one of them is requested
     const bool out = full || wantfin;
     void (*kern)(const KArgs) = single ? (out ? k_trace<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : k_trace<FLAG_SINGLE>) : (out ? k_trace<FLAG_FULL | FLAG_FINAL> : k_trace<0>);
+    const bool frames_only = ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2) && !ctx->frames_have_generic;
+    if (single && !out && !(prm->follow_threshold[1] < 0)) kern = frames_only ? k_trace<FLAG_SINGLE, true, false> : k_trace<FLAG_SINGLE, true, true>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int bpc = ctx->blocks_per_cu;
     if (bpc <= 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, lds) != hipSuccess || nb < 1) nb = 1; bpc = nb > 8 ? 8 : nb; }
