@@ -108,6 +108,7 @@ def main():
     flags = _lib.FLAG_SINGLECHILD
 
     by_kernel = [[0.0, 0], [0.0, 0], [0.0, 0]]  # k_trace, k_level_hit, k_level_phys: ms, launches
+    hit_units = [0]
 
     def step(i):
         prm = ctx.params(kw["K"], flags, 0, kw["min_travel"], kw["thr"], kw["tir"], a.seed, (rank * (a.steps + a.warmup) + i) * a.rays)
@@ -117,6 +118,7 @@ def main():
         bk = (C.c_double * 3)(); bn = (C.c_int32 * 3)(); ctx.L.rt_result_timing_by_kernel(ctx.h, bk, bn)
         for j in range(3):
             by_kernel[j][0] += bk[j]; by_kernel[j][1] += bn[j]
+        hit_units[0] += int(live[:bn[1]].sum())  # rays the nearest-hit launches of this trace went through
         return int(scat.sum()), ms.value
 
     def barrier():
@@ -127,6 +129,7 @@ def main():
     for i in range(a.warmup):
         step(i)
     by_kernel[:] = [[0.0, 0], [0.0, 0], [0.0, 0]]
+    hit_units[0] = 0
     barrier()
     t0 = time.perf_counter()
     inter = 0; kms = 0.0
@@ -144,8 +147,29 @@ def main():
         inter_all = float(inter); kms_max = kms
     if rank == 0:
         fpi = flop_per_interaction(prog[0])
+        fph = fpi - FLOP_PHYSICS  # nearest-hit search only: per ray and step, all surfaces
         kernel_s = kms / 1e3
-        ach = (inter * fpi / kernel_s) / 1e12 if kernel_s > 0 else 0.0
+        path = (inter * fpi / kernel_s) / 1e12 if kernel_s > 0 else 0.0
+        names = ("k_trace", "k_level_hit", "k_level_phys")
+        hit_ms, hit_n = by_kernel[1]
+        # dominant kernel: k_level_hit (nearest hit over all surfaces for the live rays of one step, one launch per step)
+        if hit_n > 0 and hit_ms > 0:
+            ach = (hit_units[0] * fph / (hit_ms / 1e3)) / 1e12
+            dom = {"kernel": "k_level_hit", "launches": hit_n, "avg_launch_ms": hit_ms / hit_n, "units_per_launch": hit_units[0] / hit_n,
+                   "flop_per_unit": fph, "unit_name": "ray-step (one live ray tested against all %d surfaces)" % S}
+        else:  # level path off (RT_LEVEL_STEPS=0): the persistent kernel does everything
+            ach = path
+            dom = {"kernel": "k_trace", "launches": by_kernel[0][1], "avg_launch_ms": by_kernel[0][0] / max(by_kernel[0][1], 1),
+                   "units_per_launch": inter / max(by_kernel[0][1], 1), "flop_per_unit": fpi, "unit_name": "interaction"}
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes of the same command (tools/profile_traffic.sh), bytes per launch
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))
+                if t.get("rays_per_step") == a.rays and t.get("workload") == a.workload:
+                    traffic = t["kernels"].get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         out = {
             "metric": "ray-surface interactions/sec (node) on SBC geometry", "value": inter_all / dt, "unit": "interactions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
@@ -154,11 +178,13 @@ def main():
                                    % (a.workload, S, kw["K"], kw["thr"][0], a.rays),
                        "rays_per_step_per_gpu": a.rays, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
                        "ray_surface_tests_per_s": inter_all * S / dt},
-            "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                         "traffic": None, "flop_per_interaction": fpi, "kernel": "k_trace", "kernel_ms_per_step": kms / a.steps,
-                         "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
-                                       for j, n in enumerate(("k_trace", "k_level_hit", "k_level_phys"))},
-                         "note": "FP64 vector path (no dense contraction, MFMA unused); hbm bytes/interaction is ~0 in the persistent kernel"},
+            "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                              "traffic": traffic,
+                              "note": "FP64 vector path: no dense contraction (MFMA unused), HBM traffic is two orders below the 8 TB/s roof; "
+                                      "algorithmic flop convention of SURVEY.md 8a/8d"}, **dom),
+            "roofline_path": {"achieved": path, "frac": path / FP64_VALU_PEAK_TFLOPS, "flop_per_interaction": fpi, "kernel_ms_per_step": kms / a.steps,
+                              "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
+                                            for j, n in enumerate(names)}},
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prog, origin, kw, a.seed)
