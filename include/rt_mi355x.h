@@ -146,9 +146,12 @@ int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const 
 int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int64_t n, uint64_t seed, int64_t ray_id_base,
                              double* start /*[n][3]*/, double* rays /*[n][10]*/);
 
-/* Tuning knobs (no reference counterpart): "workspace_gb" (device memory for records/queues, default 8),
- * "refill_min" (idle lanes per wave that trigger a refill = compaction cadence, default 16),
- * "blocks_per_cu" (0 = occupancy query), "nodice_chunk" (rays per pass in ray-splitting mode, default 2^20). */
+/* Tuning knobs (no reference counterpart): "workspace_gb" (device memory for records/queues, default 32),
+ * "level_steps" / "level_min_rays" (single-child runs are traced step by step for at most that many steps and while
+ * at least that many rays are live, the persistent kernel takes the rest; 24 / 32768), "hit_split", "frames" (0: the
+ * reference's formulas for every surface instead of the frame program), "refill_min" (idle lanes per wave that
+ * trigger a refill of the persistent kernel, default 4), "blocks_per_cu" (0 = occupancy query), "nodice_chunk" (rays
+ * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "release_workspace" (free the pooled device buffers). */
 int rt_set_option(rt_ctx* ctx, const char* key, double value);
 
 /* Results of the last trace. */
