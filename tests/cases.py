@@ -166,3 +166,54 @@ def mixed_geometry(cls=Surf):
     sl.append(mk('rough cylinder', 'cylinder', [np.array([0, 0, 0.]), np.array([.1, 0, 1.]), 20.], lambda p: np.reshape((p[:, 2, :] > -12) & (p[:, 2, :] <= 12), (p.shape[0], -1)), 1.5, 1.33, 'unified', 0.05,
                  unifiedparams=[.15, .7, .3, .2, .1], **fill))
     return sl
+
+
+def coaxial_scene(seed=0, cls=Surf):
+    """Random scene around a tilted axis (unit vector a, point c0): cylinders, planes normal to a, spheres centred on the
+    axis, a cone and an ellipsoid of revolution, a torus - all bounded by ranges of the axial coordinate, of the radius
+    about the axis and of the distance from a point of the axis, i.e. everything the frame program evaluates without the
+    hit point - plus one off-axis sphere and one bound the frame program must leave to the generic evaluator."""
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=3); a /= np.linalg.norm(a)
+    c0 = rng.normal(size=3) * 3
+    e1 = np.cross(a, [1.0, 0, 0]); e1 /= np.linalg.norm(e1); e2 = np.cross(a, e1)
+    Pp = np.eye(3) - np.outer(a, a)  # projector on the plane normal to the axis
+
+    def ax(p):  # axial coordinate relative to c0
+        return (p[:, 0, :] - c0[0]) * a[0] + (p[:, 1, :] - c0[1]) * a[1] + (p[:, 2, :] - c0[2]) * a[2]
+
+    def rad2(p):
+        dx = p[:, 0, :] - c0[0]; dy = p[:, 1, :] - c0[1]; dz = p[:, 2, :] - c0[2]
+        t = dx * a[0] + dy * a[1] + dz * a[2]
+        return (dx - t * a[0]) ** 2 + (dy - t * a[1]) ** 2 + (dz - t * a[2]) ** 2
+
+    def dist2(p, t):
+        q = c0 + t * a
+        return (p[:, 0, :] - q[0]) ** 2 + (p[:, 1, :] - q[1]) ** 2 + (p[:, 2, :] - q[2]) ** 2
+
+    def mk(desc, shape, pl, inb, no, ni, st='normal', ab=0.0, **kw):
+        s = cls(); s.description = desc; s.shape = shape; s.param_list = pl; s.inbounds_function = inb
+        s.n_outside = no; s.n_inside = ni; s.surface_type = st; s.absorption = ab
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+    sl = []
+    sl.append(mk('outer wall', 'cylinder', [c0 + 3.0 * a, a, 20.0], lambda p: np.reshape((ax(p) > -15) & (ax(p) <= 15), (p.shape[0], -1)), np.inf, 1.3, ab=1.0))
+    sl.append(mk('glass cylinder in', 'cylinder', [c0, -a, 6.0], lambda p: np.reshape((ax(p) >= -8) & (ax(p) < 8), (p.shape[0], -1)), 1.3, 1.5))
+    sl.append(mk('glass cylinder out', 'cylinder', [c0 - 2.0 * a, a, 6.5], lambda p: np.reshape((ax(p) >= -8) & (ax(p) < 8), (p.shape[0], -1)), 1.5, 1.3))
+    sl.append(mk('top cap', 'plane', [c0 + 15.0 * a, a], lambda p: np.reshape(rad2(p) < 400.0, (p.shape[0], -1)), np.inf, 1.3, ab=1.0))
+    sl.append(mk('bottom cap', 'plane', [c0 - 15.0 * a + 0.7 * e1, -a], lambda p: np.reshape(dist2(p, -15.0) <= 400.0, (p.shape[0], -1)), np.inf, 1.3, ab=0.6))
+    sl.append(mk('ring plane', 'plane', [c0 + 8.0 * a, a], lambda p: np.reshape((rad2(p) > 36.0) & (rad2(p) < 42.25), (p.shape[0], -1)), 1.5, 1.3))
+    sl.append(mk('lens sphere', 'sphere', [c0 + 11.0 * a, 4.0], lambda p: np.reshape(ax(p) > -1e9, (p.shape[0], -1)), 1.3, 1.6))
+    sl.append(mk('dome', 'sphere', [c0 - 8.0 * a, 6.0], lambda p: np.reshape(ax(p) < -8, (p.shape[0], -1)), 1.3, 1.5))
+    # cone about the axis, apex at c0 - 20 a: |x_perp|^2 = 0.09 (xa + 20)^2
+    Q = Pp - 0.09 * np.outer(a, a); q0 = c0 - 20.0 * a
+    sl.append(mk('cone', 'quadsurface', [Q, -2 * Q @ q0, float(q0 @ Q @ q0)], lambda p: np.reshape((ax(p) > 9) & (ax(p) < 14), (p.shape[0], -1)), 1.3, 1.7, ab=0.3))
+    # ellipsoid of revolution centred at c0 + 2 a
+    Q2 = Pp / 9.0 + np.outer(a, a) / 16.0; q2 = c0 + 2.0 * a
+    sl.append(mk('ellipsoid', 'quadsurface', [Q2, -2 * Q2 @ q2, float(q2 @ Q2 @ q2) - 1.0], lambda p: np.reshape(dist2(p, 2.0) > 9.5, (p.shape[0], -1)), 1.3, 1.45))
+    sl.append(mk('torus', 'torus', [c0 - 11.0 * a, a, 9.0, 1.5], lambda p: np.reshape((ax(p) > -12.2) & (rad2(p) > 64.0), (p.shape[0], -1)), 1.3, 1.5))
+    sl.append(mk('off-axis ball', 'sphere', [c0 + 9.0 * e1 + 4.0 * a, 2.0], lambda p: np.reshape(ax(p) > -1e9, (p.shape[0], -1)), 1.3, 2.0, ab=0.5))
+    sl.append(mk('half cylinder', 'cylinder', [c0, a, 12.0], lambda p: np.reshape((ax(p) > -3) & (ax(p) < 3) & ((p[:, 0, :] - c0[0]) * e1[0] + (p[:, 1, :] - c0[1]) * e1[1] + (p[:, 2, :] - c0[2]) * e1[2] > 0), (p.shape[0], -1)), 1.3, 1.5))
+    origin = c0 + 1.0 * a + 0.5 * e2
+    return sl, origin

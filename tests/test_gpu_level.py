@@ -1,0 +1,74 @@
+"""GPU parity of the level-synchronous path (k_level_init / k_level_hit / k_level_phys / k_level_compact + the
+persistent tail) and of the frame program, forced on with rt_set_option so that small inputs take them too.
+Through the C ABI, against the CPU oracle (which knows neither frames nor kernels)."""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+
+import cases
+from compare_util import compare_results
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_with(options, *a, **k):
+    from raytracer_amd.RayTracer2 import Context, RayTracer2
+    c = Context(0)
+    try:
+        for key, v in options.items():
+            c.set_option(key, v)
+        out = RayTracer2(*a, ctx=c, **k)
+    finally:
+        c.close()
+    r = types.SimpleNamespace(ray_interfaces=list(out[0]), absorption_table=out[1], raytable=out[2])
+    if len(out) > 3:
+        r.final = out[3]
+    return r
+
+
+@pytest.mark.parametrize("opts", [dict(level_steps=1000, level_min_rays=0), dict(level_steps=2, level_min_rays=0), dict(level_steps=0),
+                                  dict(level_steps=1000, level_min_rays=0, frames=0), dict(level_steps=1000, level_min_rays=0, hit_split=1)])
+def test_tilted_scene_records_and_final_rows(opts):
+    sl, origin = cases.coaxial_scene(2)
+    sp, rays = cases.isotropic_rays(20000, 42, origin=tuple(origin), polarized=True)
+    args = (12, 1e-7, 1e-5, -1, True, True, False)
+    got = gpu_with(opts, sp, rays.copy(), sl, *args, seed=2, compat="matlab", return_final=True)
+    ref = O.trace(sp, rays.copy(), sl, *args, seed=2, compat="matlab", final=True)
+    compare_results(ref, got, growth=3.0)
+    assert np.allclose(ref.final, got.final, rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("opts", [dict(level_steps=1000, level_min_rays=0), dict(level_steps=3, level_min_rays=0), dict(level_steps=0)])
+def test_tally_only_runs_take_the_lean_step(opts):
+    from raytracer_amd import geometries as G
+    sl = G.create_arbc_geometry(G.sbc_full_mc_specs())
+    sp, rays = cases.isotropic_rays(30000, 3, origin=(0, 0, 10))
+    args = (100, [1e-6], 1e-4, -1, False, True, False)
+    got = gpu_with(opts, sp, rays.copy(), sl, *args, seed=11, compat="matlab")
+    ref = O.trace(sp, rays.copy(), sl, *args, seed=11, compat="matlab")
+    assert ref.absorption_table.shape == got.absorption_table.shape
+    assert np.allclose(ref.absorption_table, got.absorption_table, rtol=1e-7, atol=1e-7)
+    # conservation, MATLAB/Examples/RunExamples/RunSBCGeometry.m:87-92
+    t = got.absorption_table
+    assert abs(t[:, 0:4].sum() + t[-1, 4].sum() - sp.shape[0]) < 1e-6 * sp.shape[0]
+
+
+def test_mixed_geometry_all_surface_types_level_path():
+    sp, rays = cases.isotropic_rays(30000, 21, origin=(1, 2, 3), polarized=True)
+    args = (25, 1e-7, 1e-5, 0.5, True, True, False)
+    got = gpu_with(dict(level_steps=1000, level_min_rays=0), sp, rays.copy(), cases.mixed_geometry(), *args, seed=31, compat="matlab")
+    ref = O.trace(sp, rays.copy(), cases.mixed_geometry(), *args, seed=31, compat="matlab")
+    compare_results(ref, got, growth=3.0, tol_max=1e-4)
+
+
+def test_level_path_chunked_by_workspace():
+    """a workspace too small for one pass: the level path runs chunk after chunk, results are the same"""
+    sl, origin = cases.coaxial_scene(3)
+    sp, rays = cases.isotropic_rays(40000, 43, origin=tuple(origin))
+    args = (10, 1e-7, 1e-5, -1, False, True, False)
+    a = gpu_with(dict(level_steps=1000, level_min_rays=0), sp, rays.copy(), sl, *args, seed=4, compat="matlab")
+    b = gpu_with(dict(level_steps=1000, level_min_rays=0, workspace_gb=3e-3), sp, rays.copy(), sl, *args, seed=4, compat="matlab")
+    assert a.absorption_table.shape == b.absorption_table.shape and np.allclose(a.absorption_table, b.absorption_table, rtol=1e-9, atol=1e-9)
