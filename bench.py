@@ -41,6 +41,10 @@ def build_workload(name):
         sl = G.create_arbc_geometry(G.sbc_full_mc_specs())
         origin = (0.0, 0.0, 10.0)
         kw = dict(K=100, min_travel=1e-6, thr=(1e-4, 1e-4), tir=-1.0)
+    elif name == "arbc_camera":  # camera rays through the jar, python/BubbleImageCreator.py:129
+        sl = G.create_arbc_geometry(G.ArBCSpecs())
+        origin = None
+        kw = dict(K=18, min_travel=1e-5, thr=(1e-5, 100.0), tir=-1.0)
     elif name == "sbc_lightcollection":
         sl = G.create_sbc_geometry()
         origin = (0.0, 0.6, 1.3)
@@ -104,15 +108,25 @@ def main():
     ctx = Context(local)
     ctx.set_program(*prog)
     S = prog[0].shape[0]
-    org = (C.c_double * 3)(*origin)
     flags = _lib.FLAG_SINGLECHILD
+    cam = None
+    if origin is None:  # one ray per pixel of a 3:4 sensor with about --rays pixels
+        from raytracer_amd import geometries as Gm
+        h = max(1, int(round((a.rays * 0.75) ** 0.5))); w = max(1, a.rays // h)
+        cam = Gm.arbc_camera(Gm.ArBCSpecs(cam_resolution=np.array([h, w])))
+        a.rays = h * w
+    else:
+        org = (C.c_double * 3)(*origin)
 
     by_kernel = [[0.0, 0], [0.0, 0], [0.0, 0]]  # k_trace, k_level_hit, k_level_phys: ms, launches
     hit_units = [0]
 
     def step(i):
         prm = ctx.params(kw["K"], flags, 0, kw["min_travel"], kw["thr"], kw["tir"], a.seed, (rank * (a.steps + a.warmup) + i) * a.rays)
-        ctx._check(ctx.L.rt_trace_point_source(ctx.h, org, a.rays, C.byref(prm)))
+        if cam is not None:
+            ctx._check(ctx.L.rt_trace_camera(ctx.h, C.byref(cam), C.byref(prm)))
+        else:
+            ctx._check(ctx.L.rt_trace_point_source(ctx.h, org, a.rays, C.byref(prm)))
         live, scat = ctx.step_counts(kw["K"])
         ms = C.c_double(); nl = C.c_int32(); ctx.L.rt_result_timing(ctx.h, C.byref(ms), C.byref(nl))
         bk = (C.c_double * 3)(); bn = (C.c_int32 * 3)(); ctx.L.rt_result_timing_by_kernel(ctx.h, bk, bn)
@@ -174,8 +188,8 @@ def main():
             "metric": "ray-surface interactions/sec (node) on SBC geometry", "value": inter_all / dt, "unit": "interactions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d-surface jar geometry, point source, MC single-child, K=%d, thr=%g, %d rays/step/GPU, full_output off"
-                                   % (a.workload, S, kw["K"], kw["thr"][0], a.rays),
+            "config": {"workload": "%s: %d-surface jar geometry, %s, MC single-child, K=%d, thr=%g, %d rays/step/GPU, full_output off"
+                                   % (a.workload, S, "point source" if cam is None else "camera rays generated on the device", kw["K"], kw["thr"][0], a.rays),
                        "rays_per_step_per_gpu": a.rays, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
@@ -186,7 +200,7 @@ def main():
                               "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
                                             for j, n in enumerate(names)}},
         }
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and cam is None:
             out["cpu_baseline"] = cpu_baseline(prog, origin, kw, a.seed)
         print(json.dumps(out))
     if dist is not None:

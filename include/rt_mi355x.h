@@ -146,6 +146,26 @@ int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const 
 int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int64_t n, uint64_t seed, int64_t ray_id_base,
                              double* start /*[n][3]*/, double* rays /*[n][10]*/);
 
+/* Camera of MATLAB/Examples/ImagingExamples/GenerateRaysFromCamera.m:6-7 (python/GenerateRaysFromCamera.py is not
+ * runnable) plus what the geometry builders append to every direction (createGeometry.py:1113-1122,
+ * CreateArBCGeometry.m:632-637): starting point, polarisation reference, Stokes vector. */
+enum { RT_LENS_TAN = 0, RT_LENS_THETA = 1, RT_LENS_SIN = 2 };   /* lens_type 'tan' (default) | 'theta' | 'sin', :58-67 */
+typedef struct rt_camera {
+    int32_t resolution[2];   /* pixels along i and j */
+    int32_t lens_type;       /* RT_LENS_* */
+    int32_t n_distortion;    /* number of radial distortion coefficients used (<= 8), :54-56 */
+    double pixel_pitch[2], pixel_center[2], focal_length, pitch, yaw, roll, distortion[8];
+    double position[3], polref[3], stokes[4];
+} rt_camera;
+
+/* One ray per pixel, generated in HBM, traced.  Ray id = ray_id_base + (j-1)*resolution[0] + (i-1), the row order of
+ * GenerateRaysFromCamera.m:44-46.  Replaces GenerateRaysFromCamera + the host arrays of BubbleImageCreator.py:129. */
+int rt_trace_camera(rt_ctx* ctx, const rt_camera* cam, const rt_params* prm);
+/* Rays of pixels [first, first+n) copied to the host in the reference layout, pixels[n][2] = (i, j) 1-based:
+ * the return values of GenerateRaysFromCamera.m:6 with the constant columns appended. */
+int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, int64_t n,
+                            double* start /*[n][3]*/, double* rays /*[n][10]*/, int32_t* pixels /*[n][2]*/);
+
 /* Tuning knobs (no reference counterpart): "workspace_gb" (device memory for records/queues, default 32),
  * "level_steps" / "level_min_rays" (single-child runs are traced step by step for at most that many steps and while
  * at least that many rays are live, the persistent kernel takes the rest; 24 / 32768), "hit_split", "frames" (0: the

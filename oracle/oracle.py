@@ -257,3 +257,35 @@ def poly_roots(coef):
     re = np.zeros(4); ir = np.zeros(4, np.int32)
     L.ora_poly_roots(_dp(c), C.c_int(deg), _dp(re), ir.ctypes.data_as(C.POINTER(C.c_int32)))
     return re[:deg], ir[:deg].astype(bool)
+
+
+def generate_rays_from_camera(resolution, pixel_pitch, pixel_center, focal_length, pitch=0.0, yaw=0.0, roll=0.0, radial_distortion=(), lens_type="tan"):
+    """numpy restatement of MATLAB/Examples/ImagingExamples/GenerateRaysFromCamera.m:42-81, line by line (the numpy port
+    python/GenerateRaysFromCamera.py does not run: SURVEY.md section 2).  Returns (ray_direction N x 3, pixels N x 2),
+    rows in the column-major order of i_pix(:), j_pix(:).  Parity unpinned by any executable reference."""
+    res = [int(resolution[0]), int(resolution[1])]
+    pp = np.atleast_1d(np.asarray(pixel_pitch, float)).ravel()
+    if pp.size == 1:
+        pp = np.array([pp[0], pp[0]])                                        # :38-40
+    f = float(np.atleast_1d(focal_length).ravel()[0])
+    i_pix, j_pix = np.meshgrid(np.arange(1, res[0] + 1), np.arange(1, res[1] + 1), indexing="ij")   # :44-45
+    i_pix = i_pix.ravel(order="F").astype(float); j_pix = j_pix.ravel(order="F").astype(float)   # (:)
+    pixels = np.column_stack([i_pix, j_pix]).astype(np.int64)                # :46
+    loc = np.column_stack([(pixel_center[0] - i_pix) * pp[0], np.zeros(i_pix.size) - f, -(pixel_center[1] - j_pix) * pp[1]])   # :48-50
+    d2 = np.sum(loc[:, [0, 2]] ** 2, axis=1)                                 # :52
+    rd = np.atleast_1d(np.asarray(radial_distortion, float)).ravel()
+    eff = f * (1 + sum(rd[k] * (f ** -2 * d2) ** (k + 1) for k in range(rd.size)))   # :54-56
+    with np.errstate(all="ignore"):
+        if lens_type == "theta":
+            theta = np.sqrt(d2) / eff                                        # :59-60
+        elif lens_type == "sin":
+            theta = np.arcsin(np.sqrt(d2) / eff)                             # :61-62
+        else:
+            theta = np.arctan(np.sqrt(d2) / eff)                             # :63-66
+    phi = np.arctan2(-loc[:, 2], -loc[:, 0])                                 # :69
+    rdir = np.column_stack([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)])   # :70
+    M1 = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])         # :75
+    M2 = np.array([[1, 0, 0], [0, np.cos(pitch), -np.sin(pitch)], [0, np.sin(pitch), np.cos(pitch)]])  # :76
+    M3 = np.array([[np.cos(roll), 0, np.sin(roll)], [0, 1, 0], [-np.sin(roll), 0, np.cos(roll)]])      # :77
+    M = M1 @ M2 @ M3                                                         # :79
+    return (M @ rdir.T).T, pixels                                            # :81

@@ -130,6 +130,38 @@ def _surface_fingerprint(s):
             id(getattr(s, "inbounds_function", None)))
 
 
+def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.float64(1)), follow_thresh=np.array([0, 0], dtype=np.float64),
+                 tir_handling=[], full_output=False, singlechild=True, *, compat="python", seed=None, device=0, ctx=None, ray_id_base=0,
+                 unified_maxiter=0):
+    """The camera run of python/BubbleImageCreator.py:129 without host arrays: rays are generated in HBM from the
+    rt_camera `cam` (GenerateRaysFromCamera.make_camera), traced, and reduced to the final row per pixel
+    (BubbleImageCreator.py:149-161).  Returns (absorption_table, final_rows[n_pixels][32], ray_interfaces or [])."""
+    if np.size(surfacelist) == 0:
+        raise Exception('Improper input to RayTracer2')
+    n = int(cam.resolution[0]) * int(cam.resolution[1])
+    st = np.array([[cam.stokes[0]]])
+    K, mtl, thr, tir = parse_args(np.hstack([np.zeros((1, 6)), st, np.zeros((1, 3))]), max_scat, min_travel_len, follow_thresh, tir_handling, compat)
+    for s in surfacelist:
+        if not hasattr(s, "unifiedparams") or np.size(s.unifiedparams) == 0:
+            s.unifiedparams = [0, 1, 0, 1, 0]
+        for name in _table.BULK_PROPS:
+            if not hasattr(s, name) or np.size(getattr(s, name)) == 0:
+                setattr(s, name, np.inf)
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) * (2 ** 31) + int(np.random.randint(0, 2 ** 31 - 1))
+    c = ctx if ctx is not None else get_context(device)
+    c.set_surfaces(surfacelist, nobulk=(compat == "python-strict"))
+    flags = (_lib.FLAG_FULL_OUTPUT if full_output else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | _lib.FLAG_FINAL_ROWS
+    prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
+    c._check(c.L.rt_trace_camera(c.h, C.byref(cam), C.byref(prm)))
+    res = c.results(bool(full_output), True, n)
+    ris = []
+    if full_output:
+        groups = order_records(res["step"], res["ray"], res["parent"], res["flags"], res["num_steps"])
+        ris = [_interface_from(res["rec"][g]) for g in groups if g.size]
+    return res["table"], res["final"], ris
+
+
 def get_context(device=0):
     if device not in _CTX:
         _CTX[device] = Context(device)

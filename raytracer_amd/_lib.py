@@ -11,7 +11,7 @@ FLAG_FULL_OUTPUT, FLAG_SINGLECHILD, FLAG_FINAL_ROWS = 1, 2, 4
 COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
 
 EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device",
-           "rt_trace_point_source", "rt_generate_point_source", "rt_set_option", "rt_result_num_steps", "rt_result_table",
+           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_option", "rt_result_num_steps", "rt_result_table",
            "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_final", "rt_result_timing",
            "rt_result_timing_by_kernel", "rt_device_info")
 
@@ -20,6 +20,16 @@ class Params(C.Structure):
     _fields_ = [("max_scatters", C.c_int32), ("flags", C.c_int32), ("compat", C.c_int32), ("unified_maxiter", C.c_int32),
                 ("min_travel_length", C.c_double), ("follow_threshold", C.c_double * 2), ("tir_handling", C.c_double),
                 ("seed", C.c_uint64), ("ray_id_base", C.c_int64)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("resolution", C.c_int32 * 2), ("lens_type", C.c_int32), ("n_distortion", C.c_int32),
+                ("pixel_pitch", C.c_double * 2), ("pixel_center", C.c_double * 2), ("focal_length", C.c_double),
+                ("pitch", C.c_double), ("yaw", C.c_double), ("roll", C.c_double), ("distortion", C.c_double * 8),
+                ("position", C.c_double * 3), ("polref", C.c_double * 3), ("stokes", C.c_double * 4)]
+
+
+LENS_TYPES = {"tan": 0, "theta": 1, "sin": 2}
 
 
 class RayTracerLibraryError(RuntimeError):
@@ -44,6 +54,8 @@ def load():
     L.rt_trace_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, P(Params)]
     L.rt_trace_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, P(Params)]
     L.rt_generate_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, C.c_uint64, C.c_int64, P(C.c_double), P(C.c_double)]
+    L.rt_trace_camera.argtypes = [C.c_void_p, P(Camera), P(Params)]
+    L.rt_generate_camera_rays.argtypes = [C.c_void_p, P(Camera), C.c_int64, C.c_int64, P(C.c_double), P(C.c_double), P(C.c_int32)]
     L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.rt_result_num_steps.argtypes = [C.c_void_p, P(C.c_int32)]
     L.rt_result_table.argtypes = [C.c_void_p, P(C.c_double)]

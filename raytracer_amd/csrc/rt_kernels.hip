@@ -48,11 +48,12 @@ struct Queue { double* d; int64_t* i; int32_t* m; int64_t cap; };
 
 struct KArgs {
     // input
-    int mode;               // 0: initial rays, SoA in_d[f*in_stride+i]; 1: queue of spawned rays; 2: point source generated in-kernel
+    int mode;               // 0: initial rays, SoA in_d[f*in_stride+i]; 1: queue of spawned rays; 2: point source, 3: camera rays generated in-kernel
     const double* in_d; const int64_t* in_i; const int32_t* in_m; int64_t in_stride; int64_t n_in;
     int64_t ray_id_base;    // id of ray 0 of this launch's input (modes 0, 2)
     int64_t slot_base;      // final-row index = ray_id - slot_base
     double ox, oy, oz;      // point source
+    const double* cam; int64_t cam_base; // mode 3: camera block (see rt_trace_camera), ray id of pixel 0
     unsigned long long* head;
     // spawn queue
     Queue out; unsigned long long* tail;
@@ -106,6 +107,31 @@ __device__ __forceinline__ void gen_point_ray(const KArgs& a, int64_t ray_id, V3
     r.s0 = 1; r.s1 = r.s2 = r.s3 = 0;
 }
 
+// MATLAB/Examples/ImagingExamples/GenerateRaysFromCamera.m:42-81 for pixel `pix` (column-major over (i, j) as i_pix(:),
+// j_pix(:) are, :44-46).  Camera block (doubles): [0..1] resolution, [2] lens type, [3] number of distortion terms,
+// [4..5] pixel pitch, [6..7] pixel centre, [8] focal length, [9..16] distortion, [17..25] M = M1 M2 M3 row-major
+// (:74-78, built on the host), [26..28] position, [29..31] polref, [32..35] Stokes vector.
+constexpr int CAM_DOUBLES = 40;
+__device__ __forceinline__ void gen_camera_ray(const double* cam, int64_t pix, V3& p, Ray10& r) {
+    const int64_t res0 = (int64_t)cam[0];
+    const double i_pix = (double)(pix % res0 + 1), j_pix = (double)(pix / res0 + 1), f = cam[8];
+    const double lx = (cam[6] - i_pix) * cam[4], lz = -(cam[7] - j_pix) * cam[5]; // pixel_location(:,[1 3]), :48-50
+    const double d2 = lx * lx + lz * lz;                                         // :52
+    double sum = 0, pw = 1; const double u = d2 / (f * f);
+    const int nd = (int)cam[3];
+    for (int k = 0; k < nd; k++) { pw *= u; sum += cam[9 + k] * pw; }
+    const double eff = f * (1 + sum), rr = sqrt(d2) / eff;                       // :54-56
+    const int lens = (int)cam[2];
+    const double theta = lens == 1 ? rr : (lens == 2 ? asin(rr) : atan(rr));     // :58-67
+    const double phi = atan2(-lz, -lx);                                          // :69
+    double st, ct, sph, cph; sincos(theta, &st, &ct); sincos(phi, &sph, &cph);
+    const V3 c = { st * cph, ct, st * sph };                                     // :70
+    r.d = V3{ cam[17] * c.x + cam[18] * c.y + cam[19] * c.z, cam[20] * c.x + cam[21] * c.y + cam[22] * c.z, cam[23] * c.x + cam[24] * c.y + cam[25] * c.z }; // :81
+    p = V3{ cam[26], cam[27], cam[28] };
+    r.pol = V3{ cam[29], cam[30], cam[31] };
+    r.s0 = cam[32]; r.s1 = cam[33]; r.s2 = cam[34]; r.s3 = cam[35];
+}
+
 __device__ __forceinline__ void load_queue_ray(const KArgs& a, int64_t idx, RayState& q) {
     const double* d = a.in_d; const int64_t st = a.in_stride;
     q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
@@ -119,7 +145,10 @@ __device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& 
     if (a.mode == 1) { load_queue_ray(a, idx, q); return; }
     q.ray_id = a.ray_id_base + idx; q.parent = -1; q.hash = 0; q.k = 0; q.smix_last = 1; q.six_last = 0; q.flags = RF_PRIMARY; // RayTracer2.py:258-262
     if (a.mode == 2) gen_point_ray(a, q.ray_id, q.p, q.r);
-    else {
+    else if (a.mode == 3) {
+        gen_camera_ray(a.cam, q.ray_id - a.cam_base, q.p, q.r);
+        q.r.d = (1.0 / sqrt(dot(q.r.d, q.r.d))) * q.r.d; q.r.pol = (1.0 / sqrt(dot(q.r.pol, q.r.pol))) * q.r.pol; // RayTracer2.py:221-222
+    } else {
         const double* d = a.in_d; const int64_t st = a.in_stride;
         q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
         V3 dir = V3{ d[3 * st + idx], d[4 * st + idx], d[5 * st + idx] }, pol = V3{ d[6 * st + idx], d[7 * st + idx], d[8 * st + idx] };
@@ -525,6 +554,16 @@ __global__ void k_gen_point(KArgs a, int64_t n, double* start, double* rays) {
     put_ray10(rays + i * 10, 1, 0, r);
 }
 
+__global__ void k_gen_camera(const double* cam, int64_t first, int64_t n, double* start, double* rays, int32_t* pixels) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 p; Ray10 r; gen_camera_ray(cam, first + i, p, r);
+    start[i * 3] = p.x; start[i * 3 + 1] = p.y; start[i * 3 + 2] = p.z;
+    put_ray10(rays + i * 10, 1, 0, r);
+    const int64_t res0 = (int64_t)cam[0];
+    pixels[2 * i] = (int32_t)((first + i) % res0 + 1); pixels[2 * i + 1] = (int32_t)((first + i) / res0 + 1);
+}
+
 } // namespace
 
 // ================================================================================================ host side
@@ -533,6 +572,7 @@ struct rt_ctx {
     std::string err;
     // geometry
     double* d_surf = nullptr; double* d_recs = nullptr; uint32_t* d_smeta = nullptr; double* d_lut = nullptr;
+    double* d_cam = nullptr; // camera block of the last rt_trace_camera / rt_generate_camera_rays
     double* d_prog = nullptr; int nprog_frames = 0, nprog_generic = 0; // frame program, then the all-generic program
     bool use_frames = true, frames_have_generic = false;
     bool has_rayleigh = false;
@@ -587,7 +627,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
 extern "C" void rt_free(rt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps); hipFree(ctx->d_lvl);
+    hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog); hipFree(ctx->d_cam); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps); hipFree(ctx->d_lvl);
     for (auto& pb : ctx->pool) hipFree(pb.first);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -802,6 +842,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     a.rec = (double*)b_rec.p; a.rec_cap = rec_cap; a.rec_step = (int32_t*)b_rstep.p; a.rec_ray = (int64_t*)b_rray.p; a.rec_parent = (int64_t*)b_rpar.p; a.rec_flags = (int32_t*)b_rflag.p;
     a.fin = (double*)b_fin.p; a.rows_lds = rows_lds; a.refill_min = ctx->refill_min;
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
+    a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base;
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
     void (*kphys)(const KArgs) = out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : k_level_phys<FLAG_SINGLE>;
     void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
@@ -956,6 +997,48 @@ extern "C" int rt_trace_device(rt_ctx* ctx, const double* d_soa, int64_t n, cons
 }
 extern "C" int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm) {
     return run_trace(ctx, 2, nullptr, nullptr, nullptr, origin, n, prm);
+}
+namespace {
+int upload_camera(rt_ctx* ctx, const rt_camera* cam, int64_t* n_pix) {
+    if (!cam || cam->resolution[0] < 1 || cam->resolution[1] < 1 || cam->n_distortion < 0 || cam->n_distortion > 8 || cam->lens_type < 0 || cam->lens_type > 2 ||
+        !(cam->focal_length != 0)) { ctx->err = "impropper input to GenerateRaysFromCamera"; return -1; } // GenerateRaysFromCamera.m:35 (sic)
+    double c[CAM_DOUBLES]; for (int i = 0; i < CAM_DOUBLES; i++) c[i] = 0;
+    c[0] = cam->resolution[0]; c[1] = cam->resolution[1]; c[2] = cam->lens_type; c[3] = cam->n_distortion;
+    c[4] = cam->pixel_pitch[0]; c[5] = cam->pixel_pitch[1]; c[6] = cam->pixel_center[0]; c[7] = cam->pixel_center[1]; c[8] = cam->focal_length;
+    for (int k = 0; k < cam->n_distortion; k++) c[9 + k] = cam->distortion[k];
+    // M = M1 M2 M3, GenerateRaysFromCamera.m:74-78
+    const double cy = cos(cam->yaw), sy = sin(cam->yaw), cp = cos(cam->pitch), sp = sin(cam->pitch), cr = cos(cam->roll), sr = sin(cam->roll);
+    const double M1[9] = { cy, -sy, 0, sy, cy, 0, 0, 0, 1 }, M2[9] = { 1, 0, 0, 0, cp, -sp, 0, sp, cp }, M3[9] = { cr, 0, sr, 0, 1, 0, -sr, 0, cr };
+    double T[9], M[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T[3 * i + j] = 0; for (int k = 0; k < 3; k++) T[3 * i + j] += M1[3 * i + k] * M2[3 * k + j]; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { M[3 * i + j] = 0; for (int k = 0; k < 3; k++) M[3 * i + j] += T[3 * i + k] * M3[3 * k + j]; }
+    for (int i = 0; i < 9; i++) c[17 + i] = M[i];
+    for (int i = 0; i < 3; i++) { c[26 + i] = cam->position[i]; c[29 + i] = cam->polref[i]; }
+    for (int i = 0; i < 4; i++) c[32 + i] = cam->stokes[i];
+    CK(hipSetDevice(ctx->device));
+    if (!ctx->d_cam) CK(hipMalloc(&ctx->d_cam, sizeof c));
+    CK(hipMemcpy(ctx->d_cam, c, sizeof c, hipMemcpyHostToDevice));
+    *n_pix = (int64_t)cam->resolution[0] * cam->resolution[1];
+    return 0;
+}
+} // namespace
+extern "C" int rt_trace_camera(rt_ctx* ctx, const rt_camera* cam, const rt_params* prm) {
+    int64_t n = 0;
+    if (upload_camera(ctx, cam, &n)) return -1;
+    return run_trace(ctx, 3, nullptr, nullptr, nullptr, nullptr, n, prm);
+}
+extern "C" int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, int64_t n, double* start, double* rays, int32_t* pixels) {
+    int64_t npix = 0;
+    if (upload_camera(ctx, cam, &npix)) return -1;
+    if (first < 0 || n < 1 || first + n > npix) { ctx->err = "rt_generate_camera_rays: pixel range outside the sensor"; return -1; }
+    DevBuf s, r, px; CK(dev_alloc(ctx, s, 24 * (size_t)n)); CK(dev_alloc(ctx, r, 80 * (size_t)n)); CK(dev_alloc(ctx, px, 8 * (size_t)n));
+    hipLaunchKernelGGL(k_gen_camera, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->d_cam, first, n, (double*)s.p, (double*)r.p, (int32_t*)px.p);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(start, s.p, 24 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(rays, r.p, 80 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(pixels, px.p, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 extern "C" int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int64_t n, uint64_t seed, int64_t ray_id_base, double* start, double* rays) {
     CK(hipSetDevice(ctx->device));

@@ -42,10 +42,27 @@ class ArBCSpecs(object):
         self.target_rayleigh = np.inf; self.target_abslength = np.inf
         self.reflector_type = "normal"; self.reflector_absorption = 1.0; self.reflector_unifiedparams = [0, 1, 0, 1, 0]
         self.reflector_n_inside = None
+        # camera, CreateArBCGeometry.m:135-146
+        self.cam_x = 0; self.cam_y = 0; self.cam_z = 5; self.cam_f = .8; self.cam_barreld = 0; self.cam_lenstype = 'theta'
+        self.cam_sensorsize = np.array([.1, .1]); self.cam_resolution = np.array([480, 640]); self.cam_pitch = 0; self.cam_yaw = 0; self.cam_roll = 0
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown geospec %r" % k)
             setattr(self, k, v)
+
+
+def arbc_camera(geospecs=None):
+    """The camera of CreateArBCGeometry.m:171, 632-637 as the rt_camera of rt_trace_camera: looks down the viewport axis
+    from vp_center + cam_z * vp_axis; every ray is [direction, 0 0 1, 1 0 0 0]."""
+    from .GenerateRaysFromCamera import make_camera
+    g = geospecs if geospecs is not None else ArBCSpecs()
+    vp_axis = np.array([0, -np.sin(g.vp_theta), np.cos(g.vp_theta)])
+    vp_center = np.array([0, -g.vp_s, g.vp_elev], dtype=float)
+    res = np.asarray(g.cam_resolution, float)
+    pitch = np.asarray(g.cam_sensorsize, float) / res
+    pos = vp_center + np.array([g.cam_x, 0, 0]) + g.cam_z * vp_axis + g.cam_y * np.cross(vp_axis, [1, 0, 0])
+    return make_camera(res, pitch, .5 * (1 + res), g.cam_f, g.cam_pitch + g.vp_theta - (np.pi / 2), g.cam_yaw, g.cam_roll,
+                       np.atleast_1d(g.cam_barreld), g.cam_lenstype, position=pos, polref=(0, 0, 1), stokes=(1, 0, 0, 0))
 
 
 def create_arbc_geometry(geospecs=None):

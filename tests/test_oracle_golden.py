@@ -170,3 +170,25 @@ def test_rayto_vectors():
         close(np.reshape(z[name + "_o"], (-1, M)), o, 0)
         close(np.transpose(np.reshape(z[name + "_p"], (-1, 3, M)), (0, 2, 1)), p, 1e-12)
         close(np.transpose(np.reshape(z[name + "_n"], (-1, 3, M)), (0, 2, 1)), nr, 1e-12)
+
+
+def test_oracle_camera_known_answers():
+    """GenerateRaysFromCamera.m known answers: the centre pixel looks along +y of the camera frame; the rows follow
+    i_pix(:), j_pix(:); 'theta' and 'tan' lenses agree to first order; the rotation is M1 M2 M3 (yaw about z first)."""
+    d, pix = O.generate_rays_from_camera([5, 7], 0.01, [3, 4], 0.8)
+    assert pix.shape == (35, 2) and list(pix[0]) == [1, 1] and list(pix[1]) == [2, 1] and list(pix[5]) == [1, 2]
+    c = np.nonzero((pix[:, 0] == 3) & (pix[:, 1] == 4))[0][0]
+    assert np.allclose(d[c], [0, 1, 0], atol=1e-15)
+    assert np.allclose(np.linalg.norm(d, axis=1), 1)
+    # pixel (1, 4): location x = (3-1)*pitch = +0.02 behind the pinhole -> the ray leaves towards -x; tan lens: tan(theta) = 0.02/0.8
+    k = np.nonzero((pix[:, 0] == 1) & (pix[:, 1] == 4))[0][0]
+    assert np.allclose(d[k], np.array([-0.02, 0.8, 0]) / np.hypot(0.02, 0.8), atol=1e-15)
+    dt, _ = O.generate_rays_from_camera([5, 7], 0.01, [3, 4], 0.8, lens_type="theta")
+    assert np.allclose(d, dt, atol=1e-4) and not np.allclose(d, dt, atol=1e-9)  # theta - atan(theta) ~ theta^3/3
+    dy, _ = O.generate_rays_from_camera([5, 7], 0.01, [3, 4], 0.8, yaw=np.pi / 2)
+    assert np.allclose(dy[c], [-1, 0, 0], atol=1e-15)
+    dp, _ = O.generate_rays_from_camera([5, 7], 0.01, [3, 4], 0.8, pitch=-np.pi / 2)
+    assert np.allclose(dp[c], [0, 0, -1], atol=1e-15)
+    # barrel distortion changes the effective focal length off axis only
+    db, _ = O.generate_rays_from_camera([5, 7], 0.01, [3, 4], 0.8, radial_distortion=[0.5])
+    assert np.allclose(db[c], d[c]) and db[k][0] > d[k][0]
