@@ -174,6 +174,17 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
  * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "release_workspace" (free the pooled device buffers). */
 int rt_set_option(rt_ctx* ctx, const char* key, double value);
 
+/* Record streaming (no reference counterpart: the reference keeps every rayInterfaces array in
+ * memory, python/RayTracer2.py:489-507).  With a sink set, a full_output trace hands over the records of each chunk of
+ * rays as soon as that chunk is traced instead of accumulating them: n records in device order with the same ordering
+ * keys as rt_result_records (parent = index within this call of the sink, or -1), for the rays
+ * [first_ray_id, first_ray_id + n_rays) - in single-child mode all interactions of those rays.  The pointers are valid
+ * during the call only.  Chunk size follows "workspace_gb" (single-child) / "nodice_chunk" (ray splitting).  A non-zero
+ * return stops the trace (rt_trace returns -4).  sink = NULL restores accumulation. */
+typedef int (*rt_record_sink)(void* user, int64_t n, const double* rec /*[n][RT_REC_COLS]*/, const int32_t* step, const int64_t* ray_id,
+                              const int64_t* parent, const int32_t* flags, int64_t first_ray_id, int64_t n_rays);
+int rt_set_record_sink(rt_ctx* ctx, rt_record_sink sink, void* user);
+
 /* Results of the last trace. */
 int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps);           /* rows of absorption_table (RayTracer2.py:542) */
 int rt_result_table(rt_ctx* ctx, double* table /* [num_steps][5][n_surf][2] */);

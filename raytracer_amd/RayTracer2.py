@@ -162,6 +162,47 @@ def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.flo
     return res["table"], res["final"], ris
 
 
+class npz_shards(object):
+    """record_sink that writes one .npz per chunk of rays into `directory`: for every step k of the chunk the arrays of
+    python/rayInterfaces.py:4-20 as `k<step>_<field>`, in the reference's row order within the chunk, plus `first_ray_id`
+    and `n_rays`.  `paths` lists the files written."""
+
+    def __init__(self, directory, prefix="ray_interfaces"):
+        import os
+        self.directory = directory; self.prefix = prefix; self.paths = []
+        os.makedirs(directory, exist_ok=True)
+
+    def __call__(self, chunk, first_ray_id, n_rays, ray_interfaces):
+        import os
+        out = {"first_ray_id": np.int64(first_ray_id), "n_rays": np.int64(n_rays), "n_steps": np.int64(len(ray_interfaces))}
+        for k, ri in enumerate(ray_interfaces):
+            for f, v in vars(ri).items():
+                out["k%d_%s" % (k, f)] = v
+        path = os.path.join(self.directory, "%s_%05d.npz" % (self.prefix, chunk))
+        np.savez(path, **out); self.paths.append(path)
+
+
+def _install_sink(c, record_sink, K):
+    """C callback around a Python sink(chunk_index, first_ray_id, n_rays, [rayInterfaces per step])"""
+    state = {"chunk": 0, "error": None}
+
+    def cb(user, n, rec, step, ray, parent, flags, first, nrays):
+        try:
+            n = int(n)
+            r = np.ctypeslib.as_array(rec, shape=(n, _lib.REC_COLS)); st = np.ctypeslib.as_array(step, shape=(n,))
+            ry = np.ctypeslib.as_array(ray, shape=(n,)); pa = np.ctypeslib.as_array(parent, shape=(n,)); fl = np.ctypeslib.as_array(flags, shape=(n,))
+            groups = order_records(st, ry, pa, fl, K)
+            record_sink(state["chunk"], int(first), int(nrays), [_interface_from(r[g]) for g in groups if g.size])
+            state["chunk"] += 1
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            state["error"] = e
+            return 1
+    fn = _lib.RECORD_SINK(cb)
+    c._check(c.L.rt_set_record_sink(c.h, fn, None))
+    return fn, state
+
+
 def get_context(device=0):
     if device not in _CTX:
         _CTX[device] = Context(device)
@@ -218,7 +259,7 @@ def parse_args(rays, max_scat, min_travel_len, follow_thresh, tir_handling, comp
 def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel_len=np.spacing(np.float64(1)),
                follow_thresh=np.array([0, 0], dtype=np.float64), tir_handling=[], full_output=True, singlechild=True,
                output_raytable=False, *, compat="python", seed=None, device=0, return_final=False, ray_id_base=0, ctx=None,
-               unified_maxiter=0):
+               unified_maxiter=0, record_sink=None):
     # error check inputs (python/RayTracer2.py:216-217), before any device work
     if np.size(surfacelist) == 0 or np.array(ray_startingpoints).ndim != 2 or np.array(rays).ndim != 2 or \
             np.size(ray_startingpoints, 1) != 3 or np.size(rays, 1) != 10 or np.size(ray_startingpoints, 0) != np.size(rays, 0):
@@ -251,16 +292,27 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     flags = (_lib.FLAG_FULL_OUTPUT if want_rec else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | (_lib.FLAG_FINAL_ROWS if return_final else 0)
     prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
     chunk = None
-    for attempt in range(8):
-        try:
-            c._check(c.L.rt_trace(c.h, _dp(sp), _dp(ry), n, C.byref(prm)))
-            break
-        except _lib.RayTracerLibraryError as e:
-            # ray-splitting mode cannot bound its queue/record growth in advance: on overflow retry with smaller passes
-            if getattr(e, "code", 0) != -3 or singlechild or attempt == 7:
-                raise
-            chunk = max(256, (chunk if chunk is not None else min(n, 1 << 20)) // 4)
-            c.set_option("nodice_chunk", chunk)
+    sink = None
+    if record_sink is not None:  # streaming: records leave chunk by chunk; ray_interfaces comes back empty
+        if not full_output or output_raytable or not singlechild:
+            raise ValueError("record_sink needs full_output=True, singlechild=True and output_raytable=False")
+        sink = _install_sink(c, record_sink, K)
+    try:
+        for attempt in range(8):
+            try:
+                c._check(c.L.rt_trace(c.h, _dp(sp), _dp(ry), n, C.byref(prm)))
+                break
+            except _lib.RayTracerLibraryError as e:
+                if sink is not None and sink[1]["error"] is not None:
+                    raise sink[1]["error"]
+                # ray-splitting mode cannot bound its queue/record growth in advance: on overflow retry with smaller passes
+                if getattr(e, "code", 0) != -3 or singlechild or attempt == 7:
+                    raise
+                chunk = max(256, (chunk if chunk is not None else min(n, 1 << 20)) // 4)
+                c.set_option("nodice_chunk", chunk)
+    finally:
+        if sink is not None:
+            c.L.rt_set_record_sink(c.h, C.cast(None, _lib.RECORD_SINK), None)
     res = c.results(want_rec, return_final, n)
     ns = res["num_steps"]
     base = 0 if (COMPAT[compat] & _lib.COMPAT_PY_INDEX) else 1

@@ -11,7 +11,7 @@ FLAG_FULL_OUTPUT, FLAG_SINGLECHILD, FLAG_FINAL_ROWS = 1, 2, 4
 COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
 
 EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device",
-           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_option", "rt_result_num_steps", "rt_result_table",
+           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_record_sink", "rt_set_option", "rt_result_num_steps", "rt_result_table",
            "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_final", "rt_result_timing",
            "rt_result_timing_by_kernel", "rt_device_info")
 
@@ -30,6 +30,8 @@ class Camera(C.Structure):
 
 
 LENS_TYPES = {"tan": 0, "theta": 1, "sin": 2}
+RECORD_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64, C.c_int64)
 
 
 class RayTracerLibraryError(RuntimeError):
@@ -56,6 +58,7 @@ def load():
     L.rt_generate_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, C.c_uint64, C.c_int64, P(C.c_double), P(C.c_double)]
     L.rt_trace_camera.argtypes = [C.c_void_p, P(Camera), P(Params)]
     L.rt_generate_camera_rays.argtypes = [C.c_void_p, P(Camera), C.c_int64, C.c_int64, P(C.c_double), P(C.c_double), P(C.c_int32)]
+    L.rt_set_record_sink.argtypes = [C.c_void_p, RECORD_SINK, C.c_void_p]
     L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.rt_result_num_steps.argtypes = [C.c_void_p, P(C.c_int32)]
     L.rt_result_table.argtypes = [C.c_void_p, P(C.c_double)]

@@ -586,6 +586,7 @@ struct rt_ctx {
     std::vector<double> rec; std::vector<int32_t> rec_step, rec_flags; std::vector<int64_t> rec_ray, rec_parent;
     std::vector<double> fin;
     std::vector<std::pair<void*, size_t>> pool; // cached device buffers (see DevBuf)
+    rt_record_sink sink = nullptr; void* sink_user = nullptr; // records leave chunk by chunk instead of accumulating
     double kernel_ms = 0; int n_launches = 0;
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
@@ -713,6 +714,8 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
     ctx->S = n_surf; ctx->n_atoms = n_atoms; ctx->n_code = n_code;
     return 0;
 }
+
+extern "C" int rt_set_record_sink(rt_ctx* ctx, rt_record_sink sink, void* user) { ctx->sink = sink; ctx->sink_user = user; return 0; }
 
 extern "C" int rt_set_rayleigh_lut(rt_ctx* ctx, const double* lut, int32_t n) {
     if (n < 2) { ctx->err = "rt_set_rayleigh_lut: need at least 2 entries"; return -1; }
@@ -955,6 +958,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             unsigned long long nrec = 0;
             CK(hipMemcpy(&nrec, ctx->d_counters + 2, 8, hipMemcpyDeviceToHost));
             if (nrec) {
+                if (ctx->sink) { ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear(); }
                 size_t base = ctx->rec_step.size();
                 DevBuf rows; CK(dev_alloc(ctx, rows, (size_t)REC * 8 * nrec));
                 hipLaunchKernelGGL(k_rec_to_rows, dim3((unsigned)((nrec * REC + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_rec.p, rec_cap, (int64_t)nrec, (double*)rows.p);
@@ -966,6 +970,12 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 CK(hipMemcpyAsync(ctx->rec_parent.data() + base, b_rpar.p, 8 * nrec, hipMemcpyDeviceToHost, ctx->stream));
                 CK(hipStreamSynchronize(ctx->stream));
                 for (size_t i = base; i < base + nrec; i++) if (ctx->rec_parent[i] >= 0) ctx->rec_parent[i] += (int64_t)base;
+                if (ctx->sink) { // streaming: this chunk's records (self-contained: parents are chunk-local) go to the caller now
+                    int src = ctx->sink(ctx->sink_user, (int64_t)nrec, ctx->rec.data(), ctx->rec_step.data(), ctx->rec_ray.data(), ctx->rec_parent.data(), ctx->rec_flags.data(),
+                                        prm->ray_id_base + off, m);
+                    ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
+                    if (src != 0) { ctx->err = "rt_trace: the record sink asked to stop"; rc = -4; break; }
+                }
             }
         }
         if (wantfin) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));

@@ -72,3 +72,36 @@ def test_level_path_chunked_by_workspace():
     a = gpu_with(dict(level_steps=1000, level_min_rays=0), sp, rays.copy(), sl, *args, seed=4, compat="matlab")
     b = gpu_with(dict(level_steps=1000, level_min_rays=0, workspace_gb=3e-3), sp, rays.copy(), sl, *args, seed=4, compat="matlab")
     assert a.absorption_table.shape == b.absorption_table.shape and np.allclose(a.absorption_table, b.absorption_table, rtol=1e-9, atol=1e-9)
+
+
+def test_record_streaming_npz_shards(tmp_path):
+    """with a record sink the records leave chunk by chunk; together the shards hold exactly what an
+    accumulating run returns."""
+    from raytracer_amd.RayTracer2 import Context, RayTracer2, npz_shards
+    sl, origin = cases.coaxial_scene(4)
+    sp, rays = cases.isotropic_rays(30000, 44, origin=tuple(origin), polarized=True)
+    args = (10, 1e-7, 1e-5, -1, True, True, False)
+    whole = gpu_with(dict(level_steps=1000, level_min_rays=0), sp, rays.copy(), sl, *args, seed=6, compat="matlab")
+    c = Context(0)
+    try:
+        c.set_option("workspace_gb", 0.03)  # ~7000 rays of records per chunk
+        sink = npz_shards(str(tmp_path))
+        out = RayTracer2(sp, rays.copy(), sl, *args, seed=6, compat="matlab", ctx=c, record_sink=sink)
+    finally:
+        c.close()
+    assert len(out[0]) == 0 and len(sink.paths) >= 3
+    assert np.allclose(out[1], whole.absorption_table, rtol=1e-9, atol=1e-9)
+    shards = [np.load(p) for p in sink.paths]
+    assert sum(int(z["n_rays"]) for z in shards) == sp.shape[0]
+    for k, ri in enumerate(whole.ray_interfaces):
+        parts = [z["k%d_ray_index" % k] for z in shards if "k%d_ray_index" % k in z.files]
+        got_idx = np.concatenate(parts)
+        assert got_idx.size == ri.ray_index.size
+        if k == 0:  # step 0 is in ray order in both
+            assert np.array_equal(got_idx, ri.ray_index)
+            got_p = np.concatenate([z["k0_intersection_point"] for z in shards])
+            assert np.allclose(got_p, ri.intersection_point, rtol=1e-9, atol=1e-9)
+        else:       # later steps: same rows, grouped by chunk
+            o1 = np.lexsort((np.abs(got_idx),)); o2 = np.lexsort((np.abs(ri.ray_index),))
+            got_l = np.concatenate([z["k%d_distance_traveled" % k] for z in shards if "k%d_distance_traveled" % k in z.files])
+            assert np.array_equal(got_idx[o1], ri.ray_index[o2]) and np.allclose(got_l[o1], ri.distance_traveled[o2], rtol=1e-8, atol=1e-8)  # the chunks take the persistent kernel, the whole run the level kernels
