@@ -174,6 +174,7 @@ RT_HD bool inbounds(const Geom& G, const BRec& first, int off, int len, V3 p) {
 }
 
 } // namespace rt
+#include <cmath>
 #include <vector>
 namespace rt {
 #if defined(__HIPCC__)
@@ -668,6 +669,17 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
             V3 u = F.xa * ax - x, v = F.da * ax - d;
             F.a = dot(v, v); F.hb = dot(u, v); F.uu = dot(u, u); F.xd = dot(x, d); F.xx = dot(x, x);
             F.ida = rt_rcp(F.da); F.ia = rt_rcp(F.a); F.sda = isgn(F.da);
+            if (mlo & (1u << 16)) { // bounding box of the members: radius <= sqrt(w7), w8 <= axial <= w9.  Nobody gets there before its best hit: skip them all
+                const double a_lo = R.w[8], a_hi = R.w[9];
+                const double ta = (a_lo - F.xa) * F.ida, tb = (a_hi - F.xa) * F.ida;
+                double lo = fmin(ta, tb), hi = fmax(ta, tb);
+                if (RT_ANY(F.sda == 0)) { if (F.sda == 0) { const bool in = (F.xa >= a_lo) & (F.xa <= a_hi); lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; } }
+                const double disc = F.hb * F.hb - F.a * (F.uu - R.w[7]), sq = rt_sqrt(disc);
+                lo = fmax(lo, (-F.hb - sq) * F.ia); hi = fmin(hi, (sq - F.hb) * F.ia); // NaN (tangent, or ray along the axis) leaves the bound as it is
+                lo = fmax(lo, 0.0); hi = fmin(hi, h.l);
+                const bool reach = act & (disc >= 0) & (lo <= hi);
+                if (!RT_ANY(reach)) i += (int)((mlo >> 4) & 0xFFFu);
+            }
             continue;
         }
         if (kind == PK_GENERIC) {
@@ -819,6 +831,60 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
         for (int s = 0; s < S; s++) if (fr[s] >= 0) frames[fr[s]].members++;
         for (int s = 0; s < S; s++) if (fr[s] >= 0 && frames[fr[s]].members < 2) fr[s] = -1; // a frame must pay for itself
     }
+    // one atom as a one-sided bound on a frame coordinate, if it is one
+    auto atom_range = [&](uint32_t ins, const Frame& f, int& ck, double& t, bool& upper, double& bound, bool& incl) -> bool {
+        const double* a = atoms + (size_t)(ins & 0xFFFFFFu) * ATOM; const int kind = (int)a[0], cmp = (int)a[1]; const double rhs = a[2];
+        incl = (cmp == 1 || cmp == 3); upper = (cmp == 0 || cmp == 1); t = 0.0;
+        if (cmp <= 3 && (kind == 3 || kind == 1)) { // linear: c.p cmp rhs
+            V c = kind == 3 ? V{ (int)a[3] == 0 ? 1.0 : 0.0, (int)a[3] == 1 ? 1.0 : 0.0, (int)a[3] == 2 ? 1.0 : 0.0 } : V{ a[9], a[10], a[11] };
+            const double lam = dt(c, f.ax);
+            if (lam != 0 && nrm(sub(c, mul(lam, f.ax))) <= TOL * nrm(c)) { // c.p = lam (xa + c0.a^)
+                bound = rhs / lam - dt(f.c0, f.ax); if (lam < 0) upper = !upper;
+                ck = FA_AXIAL; return true;
+            }
+        } else if (cmp <= 3 && kind == 0) { // quadratic: p'Ap + b.p cmp rhs
+            const double A[9] = { a[3], 0.5 * a[6], 0.5 * a[7], 0.5 * a[6], a[4], 0.5 * a[8], 0.5 * a[7], 0.5 * a[8], a[5] }; V b = V{ a[9], a[10], a[11] };
+            double al, ga, pa, k0;
+            if (revolution_form(f, A, b, al, ga, pa, k0)) {
+                double scale = fmax(fabs(al), fabs(ga));
+                if (al != 0 && fabs(ga) <= TOL * scale && fabs(pa) <= TOL * scale * (1.0 + nrm(f.c0))) { // al |x_perp|^2 + k0
+                    if (al < 0) upper = !upper;
+                    bound = (rhs - k0) / al; ck = FA_RADIAL2; return true;
+                } else if (al != 0 && fabs(ga - al) <= TOL * scale) { // al (|x_perp|^2 + xa^2) + pa xa + k0 = al |x - t a^|^2 + k0 - al t^2
+                    t = -pa / (2 * al); if (al < 0) upper = !upper;
+                    bound = (rhs - k0) / al + t * t; ck = FA_DIST2; return true;
+                }
+            }
+        }
+        return false;
+    };
+    // Superset of where a bounds program can be true, as a box in frame coordinates (radius^2 <= r2, lo <= axial <= hi):
+    // the program evaluated over boxes - atom: its half-space or everything, AND: intersection, OR: hull, anything else: everything.
+    struct Box { double r2, lo, hi; };
+    auto program_box = [&](int s, const Frame& f) {
+        const double* r = table + (size_t)s * ROW; const int off = (int)r[27], len = (int)r[28];
+        const Box all{ INFINITY, -INFINITY, INFINITY };
+        std::vector<Box> st;
+        for (int i = off; i < off + len; i++) {
+            const uint32_t op = code[i] >> 24;
+            if (op == 1) {
+                Box b = all; int ck; double t, bound; bool upper, incl;
+                if (atom_range(code[i], f, ck, t, upper, bound, incl) && upper) {
+                    if (ck == FA_AXIAL) b.hi = bound;
+                    else if (ck == FA_RADIAL2) b.r2 = bound;
+                    else { b.r2 = bound; const double d = sqrt(fmax(bound, 0.0)); b.lo = t - d; b.hi = t + d; }
+                } else if (atom_range(code[i], f, ck, t, upper, bound, incl) && ck == FA_AXIAL) b.lo = bound;
+                st.push_back(b);
+            } else if ((op == 2 || op == 3) && st.size() >= 2) {
+                Box y = st.back(); st.pop_back(); Box& x = st.back();
+                if (op == 2) { x.r2 = fmin(x.r2, y.r2); x.lo = fmax(x.lo, y.lo); x.hi = fmin(x.hi, y.hi); }
+                else { x.r2 = fmax(x.r2, y.r2); x.lo = fmin(x.lo, y.lo); x.hi = fmax(x.hi, y.hi); }
+            } else if (op == 5) st.push_back(all);
+            else if (op == 6) st.push_back(Box{ 0.0, INFINITY, -INFINITY });
+            else { st.clear(); st.push_back(all); break; } // NOT, XOR: no claim
+        }
+        return st.size() == 1 ? st[0] : all;
+    };
     // bounds of a frame member: conjunction of ranges of frame coordinates (inline) + residual generic program
     auto member_bounds = [&](int s, const Frame& f, uint64_t& meta, double* aw) {
         const double* r = table + (size_t)s * ROW; const int off = (int)r[27], len = (int)r[28];
@@ -836,29 +902,8 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
             return true;
         };
         for (uint32_t ins : conj) {
-            const double* a = atoms + (size_t)(ins & 0xFFFFFFu) * ATOM; const int kind = (int)a[0], cmp = (int)a[1]; const double rhs = a[2];
-            bool done = false;
-            if (cmp <= 3 && (kind == 3 || kind == 1)) { // linear: c.p cmp rhs
-                V c = kind == 3 ? V{ (int)a[3] == 0 ? 1.0 : 0.0, (int)a[3] == 1 ? 1.0 : 0.0, (int)a[3] == 2 ? 1.0 : 0.0 } : V{ a[9], a[10], a[11] };
-                const double lam = dt(c, f.ax);
-                if (lam != 0 && nrm(sub(c, mul(lam, f.ax))) <= TOL * nrm(c)) { // c.p = lam (xa + c0.a^)
-                    const double bound = rhs / lam - dt(f.c0, f.ax); bool upper = (cmp == 0 || cmp == 1); if (lam < 0) upper = !upper;
-                    done = narrow(FA_AXIAL, 0.0, upper, bound, cmp == 1 || cmp == 3);
-                }
-            } else if (cmp <= 3 && kind == 0) { // quadratic: p'Ap + b.p cmp rhs
-                const double A[9] = { a[3], 0.5 * a[6], 0.5 * a[7], 0.5 * a[6], a[4], 0.5 * a[8], 0.5 * a[7], 0.5 * a[8], a[5] }; V b = V{ a[9], a[10], a[11] };
-                double al, ga, pa, k0;
-                if (revolution_form(f, A, b, al, ga, pa, k0)) {
-                    double scale = fmax(fabs(al), fabs(ga));
-                    if (al != 0 && fabs(ga) <= TOL * scale && fabs(pa) <= TOL * scale * (1.0 + nrm(f.c0))) { // al |x_perp|^2 + k0
-                        bool upper = (cmp == 0 || cmp == 1); if (al < 0) upper = !upper;
-                        done = narrow(FA_RADIAL2, 0.0, upper, (rhs - k0) / al, cmp == 1 || cmp == 3);
-                    } else if (al != 0 && fabs(ga - al) <= TOL * scale) { // al (|x_perp|^2 + xa^2) + pa xa + k0 = al |x - t a^|^2 + k0 - al t^2
-                        const double t = -pa / (2 * al); bool upper = (cmp == 0 || cmp == 1); if (al < 0) upper = !upper;
-                        done = narrow(FA_DIST2, t, upper, (rhs - k0) / al + t * t, cmp == 1 || cmp == 3);
-                    }
-                }
-            }
+            int ck; double t, bound; bool upper, incl;
+            bool done = atom_range(ins, f, ck, t, upper, bound, incl) && narrow(ck, t, upper, bound, incl);
             if (!done) rest.push_back(ins);
         }
         meta |= (uint64_t)rg.size() << 16;
@@ -873,10 +918,35 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
             meta |= ((uint64_t)first << 32) | ((uint64_t)cnt << 52);
         }
     };
+    // extent of a member in frame coordinates from its shape and inline ranges (a superset is fine): radius^2 <= r2, lo <= axial <= hi
+    auto member_extent = [&](uint64_t meta, const double* w, const Box& pb, double& r2, double& lo, double& hi) {
+        const uint32_t mlo = (uint32_t)meta, kind = mlo & 15u, na = (mlo >> 16) & 3u;
+        double A_lo = pb.lo, A_hi = pb.hi, R_hi = pb.r2; (void)na;
+        // rho^2(x) = -(ga x^2 + pa x + Rp) / al of a quadric of revolution: maximum over [A_lo, A_hi]
+        auto quad_max = [&](double al, double ga, double pa, double Rp) {
+            if (al == 0) return (double)INFINITY;
+            const double qa = -ga / al, qb = -pa / al, qc = -Rp / al; // rho^2 = qa x^2 + qb x + qc
+            double m = -INFINITY;
+            const double ends[2] = { A_lo, A_hi };
+            for (double x : ends) { if (std::isinf(x)) { if (qa > 0 || (qa == 0 && qb != 0)) return (double)INFINITY; } else m = fmax(m, (qa * x + qb) * x + qc); }
+            if (qa < 0) { const double xv = -qb / (2 * qa); if (xv >= A_lo && xv <= A_hi) m = fmax(m, (qa * xv + qb) * xv + qc); }
+            else if (qa == 0 && qb == 0) m = fmax(m, qc);
+            return m;
+        };
+        lo = A_lo; hi = A_hi; r2 = INFINITY;
+        if (kind == PK_PLANE) { lo = fmax(lo, w[0]); hi = fmin(hi, w[0]); }
+        else if (kind == PK_CYL) r2 = w[1];
+        else if (kind == PK_SPHERE) { const double t = w[0], rr = fabs(w[1]); lo = fmax(lo, t - rr); hi = fmin(hi, t + rr); A_lo = lo; A_hi = hi; r2 = quad_max(1.0, 1.0, -2 * t, w[2]); }
+        else if (kind == PK_TORUS) { const double t = w[0], R1 = fabs(w[1]), rr = fabs(w[2]); lo = fmax(lo, t - rr); hi = fmin(hi, t + rr); r2 = (R1 + rr) * (R1 + rr); }
+        else if (kind == PK_QUAD) r2 = quad_max(w[0], w[1], w[2], w[3]);
+        r2 = fmin(r2, R_hi);
+    };
     for (size_t f = 0; f < frames.size(); f++) {
         if (frames[f].members < 2) continue;
         const Frame& F = frames[f];
-        { double w[6] = { F.c0.x, F.c0.y, F.c0.z, F.ax.x, F.ax.y, F.ax.z }; put((uint64_t)PK_FRAME, w, 6); }
+        size_t frec;
+        { double w[6] = { F.c0.x, F.c0.y, F.c0.z, F.ax.x, F.ax.y, F.ax.z }; frec = put((uint64_t)PK_FRAME, w, 6); }
+        double box_r2 = 0, box_lo = INFINITY, box_hi = -INFINITY; int nmem = 0;
         for (int s = 0; s < S; s++) {
             if (fr[s] != (int)f) continue;
             const double* r = table + (size_t)s * ROW; const int shape = (int)r[0];
@@ -889,6 +959,14 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
             else { meta |= PK_QUAD; double al, ga, pa, k0; revolution_form(F, r + 2, mk(r + 11), al, ga, pa, k0); w[0] = al; w[1] = ga; w[2] = pa; w[3] = k0 + r[14]; }
             member_bounds(s, F, meta, w + 6);
             put(meta, w, PREC - 1);
+            double r2, lo, hi; member_extent(meta, w, program_box(s, F), r2, lo, hi);
+            box_r2 = fmax(box_r2, r2); box_lo = fmin(box_lo, lo); box_hi = fmax(box_hi, hi); nmem++;
+        }
+        if (nmem < 4096 && !(std::isinf(box_r2) && std::isinf(box_lo) && std::isinf(box_hi)) && !std::isnan(box_r2)) { // bounding box of the frame's members, a little wider than computed
+            uint64_t meta = (uint64_t)PK_FRAME | ((uint64_t)nmem << 4) | (1ull << 16);
+            memcpy(&prog[frec], &meta, 8);
+            const double span = std::isinf(box_hi - box_lo) ? 0.0 : (box_hi - box_lo);
+            prog[frec + 7] = box_r2 * (1 + 1e-9) + 1e-12; prog[frec + 8] = box_lo - 1e-9 * (fabs(box_lo) + span) - 1e-12; prog[frec + 9] = box_hi + 1e-9 * (fabs(box_hi) + span) + 1e-12;
         }
     }
     for (int s = 0; s < S; s++) if (fr[s] < 0) put((uint64_t)PK_GENERIC | ((uint64_t)(uint32_t)s << 4), nullptr, 0);

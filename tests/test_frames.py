@@ -23,7 +23,7 @@ def program(sl, frames=True):
     dst = np.zeros((4 * len(sl) + 8, 16)); dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     n = H.lib().hs_program(dp(tab), tab.shape[0], dp(atoms), code.ctypes.data_as(C.POINTER(C.c_uint32)), int(frames), dp(dst), dst.shape[0])
     meta = dst[:n, 0].copy().view(np.uint64)
-    return [dict(kind=KINDS[int(m) & 15], surf=(int(m) >> 4) & 0xFFF, natoms=(int(m) >> 16) & 3, residual=int(m) >> 52) for m in meta]
+    return [dict(kind=KINDS[int(m) & 15], surf=(int(m) >> 4) & 0xFFF, natoms=(int(m) >> 16) & 3, residual=int(m) >> 52, words=dst[i].copy()) for i, m in enumerate(meta)]
 
 
 def test_program_of_the_jar_geometry():
@@ -34,6 +34,13 @@ def test_program_of_the_jar_geometry():
     assert sorted(r["surf"] for r in pr if r["kind"] != "FRAME") == list(range(39))  # every surface exactly once
     assert sum(1 for r in pr if r["residual"]) <= 4
     assert all(r["kind"] == "GENERIC" for r in program(sl, frames=False)) and len(program(sl, frames=False)) == 39
+    # bounding boxes of the frames' members (a wave skips a frame nobody can reach before its best hit): the z frame holds
+    # everything up to the pressure vessel (radius 30, from z = -20 up), the camera frame the can around the viewport
+    fr = [r for r in pr if r["kind"] == "FRAME"]
+    assert [r["surf"] for r in fr] == [22, 17] and all(r["natoms"] & 1 for r in fr)   # member counts, "has box" flag
+    assert abs(np.sqrt(fr[0]["words"][7]) - 30) < 1e-6 and abs(fr[0]["words"][8] + 20) < 1e-6 and np.isinf(fr[0]["words"][9])
+    g = G.sbc_full_mc_specs()
+    assert abs(np.sqrt(fr[1]["words"][7]) - g.vp_flange_rad) < 1e-6 and fr[1]["words"][8] < 0 < fr[1]["words"][9] < 2 * g.vp_can_OAL
 
 
 def test_program_of_a_tilted_scene():
