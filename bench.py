@@ -93,13 +93,18 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: raytracer_amd has no CPU path")
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: raytracer_amd has no CPU path")
-    torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
 
     import ctypes as C
     from raytracer_amd import _lib
@@ -153,7 +158,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt, float(inter), kms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(inter), kms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); inter_all = float(tsum[1]); kms_max = float(tmax[2])
