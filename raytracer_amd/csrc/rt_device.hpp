@@ -639,7 +639,9 @@ RT_HD void frame_torus_flush(const Geom& G, const Prm& P, const FrameQ& F, udptr
         for (int m = 0; m < 4; m += 2) {
             const uint32_t s0 = (uint32_t)(sg >> (2 * m)) & 3u, s1 = (uint32_t)(sg >> (2 * m + 2)) & 3u;
             const int o0 = -flip * (s0 == 1u ? 1 : -1), o1 = -flip * (s1 == 1u ? 1 : -1);
-            frame_candidates<true>(G, P, F, R, mlo, mhi, sp, d, six_last, mine, q[m], q[m + 1], o0, o1, s0 != 0u, s1 != 0u, h);
+            const double y0 = q[m], y1 = q[m + 1];
+            if (!RT_ANY(mine & ((y0 == y0) | (y1 == y1)))) continue; // this quadratic factor has no real roots for anybody
+            frame_candidates<true>(G, P, F, R, mlo, mhi, sp, d, six_last, mine, y0, y1, o0, o1, s0 != 0u, s1 != 0u, h);
         }
     }
     rt_wave_sync();
@@ -722,17 +724,19 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
             const double t = R.w[1], R1 = R.w[2], r2 = R.w[3];
             const int n = (int)((mlo >> 4) & 0xFFFu);
             const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0;
-            const double re = fabs(r2) * (1 + 1e-9), Ro = fabs(R1) + re, Ri = fabs(R1) - re;
-            const double xa0 = F.xa - t;
-            const double ta = (-re - xa0) * F.ida, tb = (re - xa0) * F.ida;
+            // slab and annulus that hold the bounded part of the torus: w13 <= axial <= w14 (frame coordinate), radius^2 >= w15,
+            // radius <= |R1| + |r2| - the torus' own extent cut down by its range bounds on the host; everything 1e-9 wider
+            const double Ro = (fabs(R1) + fabs(r2)) * (1 + 1e-9), Ri2 = R.w[15];
+            const double ta = (R.w[13] - F.xa) * F.ida, tb = (R.w[14] - F.xa) * F.ida;
             double lo = fmin(ta, tb), hi = fmax(ta, tb);
-            if (RT_ANY(F.sda == 0)) { if (F.sda == 0) { const bool in = fabs(xa0) <= re; lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; } }
+            if (RT_ANY(F.sda == 0)) { if (F.sda == 0) { const bool in = (F.xa >= R.w[13]) & (F.xa <= R.w[14]); lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; } }
             const double disc = F.hb * F.hb - F.a * (F.uu - Ro * Ro), sq = rt_sqrt(disc);
             const bool qpos = F.a > 0;
             lo = qpos ? fmax(lo, (-F.hb - sq) * F.ia) : lo; hi = qpos ? fmin(hi, (sq - F.hb) * F.ia) : hi;
             lo = fmax(lo, lmin); hi = fmin(hi, h.l);
             bool maybe = act & (disc >= 0) & (lo <= hi);
-            if (Ri > 0) maybe = maybe & !(((F.a * lo + 2 * F.hb) * lo + F.uu < Ri * Ri) & ((F.a * hi + 2 * F.hb) * hi + F.uu < Ri * Ri));
+            maybe = maybe & !(((F.a * lo + 2 * F.hb) * lo + F.uu < Ri2) & ((F.a * hi + 2 * F.hb) * hi + F.uu < Ri2)); // radius^2 is convex in l
+            const double xa0 = F.xa - t;
             const unsigned long long mb = RT_BALLOT(maybe);
             if (mb != 0ull) {
                 const int cnt = __builtin_popcountll(mb);
@@ -886,7 +890,7 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
         return st.size() == 1 ? st[0] : all;
     };
     // bounds of a frame member: conjunction of ranges of frame coordinates (inline) + residual generic program
-    auto member_bounds = [&](int s, const Frame& f, uint64_t& meta, double* aw) {
+    auto member_bounds = [&](int s, const Frame& f, uint64_t& meta, double* aw, int max_atoms) {
         const double* r = table + (size_t)s * ROW; const int off = (int)r[27], len = (int)r[28];
         std::vector<uint32_t> conj; bool pure = true; int depth = 0;
         for (int i = off; i < off + len && pure; i++) { const uint32_t op = code[i] >> 24; if (op == 1) { conj.push_back(code[i]); depth++; } else if (op == 2) depth--; else pure = false; }
@@ -895,7 +899,7 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
         std::vector<Range> rg; std::vector<int> rkind; std::vector<uint32_t> rest;
         auto narrow = [&](int kind, double t, bool upper, double bound, bool incl) {
             size_t j = 0; for (; j < rg.size(); j++) if (rkind[j] == kind && (kind != FA_DIST2 || rg[j].t == t)) break;
-            if (j == rg.size()) { if (rg.size() == 3) return false; rg.push_back(Range{ true, -INFINITY, INFINITY, false, false, t }); rkind.push_back(kind); }
+            if (j == rg.size()) { if ((int)rg.size() == max_atoms) return false; rg.push_back(Range{ true, -INFINITY, INFINITY, false, false, t }); rkind.push_back(kind); }
             Range& R = rg[j];
             if (upper) { if (bound < R.hi || (bound == R.hi && !incl)) { R.hi = bound; R.ihi = incl; } }
             else { if (bound > R.lo || (bound == R.lo && !incl)) { R.lo = bound; R.ilo = incl; } }
@@ -957,7 +961,16 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
             else if (shape == SH_SPHERE) { meta |= PK_SPHERE; const double t = dt(sub(mk(r + 2), F.c0), F.ax); w[0] = t; w[1] = r[5]; w[2] = t * t - r[5] * r[5]; }
             else if (shape == SH_TORUS) { meta |= PK_TORUS; w[0] = dt(sub(mk(r + 2), F.c0), F.ax); w[1] = r[8]; w[2] = r[9]; w[3] = r[2]; w[4] = r[3]; w[5] = r[4]; }
             else { meta |= PK_QUAD; double al, ga, pa, k0; revolution_form(F, r + 2, mk(r + 11), al, ga, pa, k0); w[0] = al; w[1] = ga; w[2] = pa; w[3] = k0 + r[14]; }
-            member_bounds(s, F, meta, w + 6);
+            member_bounds(s, F, meta, w + 6, shape == SH_TORUS ? 2 : 3);
+            if (shape == SH_TORUS) { // prefilter slab / inner radius: the torus' own extent cut down by its range bounds
+                const Box pb = program_box(s, F);
+                const double t = w[0], R1 = fabs(w[1]), rr = fabs(w[2]) * (1 + 1e-9);
+                double alo = fmax(t - rr, pb.lo), ahi = fmin(t + rr, pb.hi), ri = fmax(R1 - rr, 0.0), ri2 = ri * ri;
+                const uint32_t na = (uint32_t)(meta >> 16) & 3u;
+                for (uint32_t j = 0; j < na; j++) if (((uint32_t)(meta >> (20 + 4 * j)) & 3u) == FA_RADIAL2) ri2 = fmax(ri2, w[6 + 3 * j]); // lower bound of a radial range
+                const double pad = 1e-9 * (fabs(alo) + fabs(ahi) + rr);
+                w[12] = alo - pad; w[13] = ahi + pad; w[14] = ri2 * (1 - 1e-9);
+            }
             put(meta, w, PREC - 1);
             double r2, lo, hi; member_extent(meta, w, program_box(s, F), r2, lo, hi);
             box_r2 = fmax(box_r2, r2); box_lo = fmin(box_lo, lo); box_hi = fmax(box_hi, hi); nmem++;
