@@ -199,7 +199,7 @@ def main():
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                               "traffic": traffic,
-                              "note": "FP64 vector path: no dense contraction (MFMA unused), HBM traffic is two orders below the 8 TB/s roof; "
+                              "note": "FP64 vector path: no dense contraction (MFMA unused), HBM traffic is below the roof (profiles/traffic.json); "
                                       "algorithmic flop convention of SURVEY.md 8a/8d"}, **dom),
             "roofline_path": {"achieved": path, "frac": path / FP64_VALU_PEAK_TFLOPS, "flop_per_interaction": fpi, "kernel_ms_per_step": kms / a.steps,
                               "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
