@@ -692,11 +692,13 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
     build_program(table, n_surf, atoms, code, true, recs, smeta, prog);
     build_program(table, n_surf, atoms, code, false, recs, smeta, prog_generic);
     finish_device_tables(recs);
+#ifdef RT_EXPERIMENTS
     if (const char* sk = getenv("RT_DEBUG_SKIP_KINDS")) { // timing experiments only (results are wrong): drop program records by kind
         const unsigned mask = (unsigned)atoi(sk); std::vector<double> kept;
         for (size_t i = 0; i + PREC <= prog.size(); i += PREC) { uint64_t m; memcpy(&m, &prog[i], 8); if (i + PREC == prog.size() || !((mask >> (m & 15u)) & 1u)) kept.insert(kept.end(), prog.begin() + i, prog.begin() + i + PREC); }
         prog.swap(kept);
     }
+#endif
     ctx->frames_have_generic = false;
     for (size_t i = 0; i + PREC < prog.size(); i += PREC) { uint64_t m; memcpy(&m, &prog[i], 8); if ((m & 15u) == PK_GENERIC) ctx->frames_have_generic = true; }
     ctx->nprog_frames = (int)(prog.size() / PREC) - 1; ctx->nprog_generic = (int)(prog_generic.size() / PREC) - 1;
