@@ -108,7 +108,7 @@ typedef struct rt_params {
 /* Final row per initial ray (the reduction python/BubbleImageCreator.py:149-161 + finalRays.py makes from
  * ray_interfaces: last record of each ray id), RT_FINAL_COLS doubles:
  *  [0..2] position of last interaction (start point if none) [3..5] direction [6..8] polref [9..12] Stokes s0..s3
- *  of the ray arriving there, [13..15] surface normal, [16] surface_index (reference convention) [17] orientation
+ *  of the ray arriving there, [13..15] surface normal, [16] surface_index (reference convention: number * orientation) [17] orientation
  *  [18] ray_index [19] number of interactions [20] s0 still followed after it
  *  [21] status: 0 escaped geometry, 1 absorbed / below threshold, 2 max_scatters reached, 3 none (never hit)
  *  [22..24] direction, [25..27] polref, [28..30] s1..s3 of the ray followed after it (refracted child if followed,
@@ -185,6 +185,33 @@ typedef int (*rt_record_sink)(void* user, int64_t n, const double* rec /*[n][RT_
                               const int64_t* parent, const int32_t* flags, int64_t first_ray_id, int64_t n_rays);
 int rt_set_record_sink(rt_ctx* ctx, rt_record_sink sink, void* user);
 
+/* Image formation after the two traces of BubbleImageCreator: every LED ray that ends on one of `surfaces` gives a
+ * Gaussian-weighted share of its intensity to the camera ray ending nearest to it on the same surface.  Replaces the
+ * O(N_led * N_cam) loop of python/BubbleImageCreator.py:278-357 (MATLAB kept there as comments; the numpy port stops
+ * at :250) with a uniform-grid search on the device; the sequential rule of :302-311 is reproduced exactly, the
+ * "distance == 0 means unset" sentinel included.  cam_rows / led_rows are final rows (RT_FINAL_COLS doubles each, see
+ * above) of the camera and LED traces; `surfaces` lists the light-giving surfaces in the convention of column [16]
+ * (sign ignored, as :287-288 compare both signs).  Rows with no interaction, with a non-finite end point or on other
+ * surfaces take no part.  Outputs: pixel_intensity[n_cam] (the sum of :343-349, accumulated with atomics: order of
+ * addition differs from run to run at the 1e-16 level); optional per LED ray: led_cam = matched camera row or -1,
+ * led_dist = its distance, led_add = the intensity it added (int_addition of :338; summing led_add by led_cam in LED
+ * order reproduces the reference's order of addition).  With RT_MATCH_DEVICE_POINTERS every array argument except
+ * `surfaces` is a device pointer (e.g. torch tensors) and nothing crosses PCIe. */
+typedef struct rt_match_params {
+    double max_dist;          /* 5              :321  pairs further apart give nothing; also the grid cell size */
+    double angle_den;         /* 2*10*pi/180    :338  denominator under (angle between the two rays)^2 */
+    double cam_incidence_den; /* 2*45*pi/180    :338  under (camera ray's incident angle)^2 */
+    double led_incidence_den; /* 2*45*pi/180    :338  under (LED ray's incident angle)^2 */
+    double dist_den;          /* 2*2^2          :338  under distance^2 */
+    int32_t flags;            /* RT_MATCH_* */
+    int32_t reserved;
+} rt_match_params;
+enum { RT_MATCH_DEVICE_POINTERS = 1 };
+int rt_match_endpoints(rt_ctx* ctx, const double* cam_rows /*[n_cam][RT_FINAL_COLS]*/, int64_t n_cam, const double* led_rows /*[n_led][RT_FINAL_COLS]*/,
+                       int64_t n_led, const int32_t* surfaces, int32_t n_surfaces, const rt_match_params* mp,
+                       double* pixel_intensity /*[n_cam]*/, int64_t* led_cam /*[n_led] or NULL*/, double* led_dist /*[n_led] or NULL*/,
+                       double* led_add /*[n_led] or NULL*/);
+
 /* Results of the last trace. */
 int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps);           /* rows of absorption_table (RayTracer2.py:542) */
 int rt_result_table(rt_ctx* ctx, double* table /* [num_steps][5][n_surf][2] */);
@@ -194,7 +221,7 @@ int rt_result_num_records(rt_ctx* ctx, int64_t* n);
 int rt_result_records(rt_ctx* ctx, double* rec /*[n][RT_REC_COLS]*/, int32_t* step /*[n]*/,
                       int64_t* ray_id /*[n]*/, int64_t* parent /*[n]*/, int32_t* flags /*[n]*/);
 int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);
-/* kernel time of the last trace measured with HIP events on the context's stream, and launch count */
+/* kernel time of the last trace (or rt_match_endpoints call) measured with HIP events on the context's stream, and launch count */
 int rt_result_timing(rt_ctx* ctx, double* kernel_ms, int32_t* n_launches);
 /* the same split by kernel: [0] k_trace (persistent bounce kernel), [1] k_level_hit, [2] k_level_phys */
 int rt_result_timing_by_kernel(rt_ctx* ctx, double ms[3], int32_t launches[3]);

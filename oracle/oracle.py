@@ -289,3 +289,60 @@ def generate_rays_from_camera(resolution, pixel_pitch, pixel_center, focal_lengt
     M3 = np.array([[np.cos(roll), 0, np.sin(roll)], [0, 1, 0], [-np.sin(roll), 0, np.cos(roll)]])      # :77
     M = M1 @ M2 @ M3                                                         # :79
     return (M @ rdir.T).T, pixels                                            # :81
+
+
+class FinalRays(object):
+    """python/finalRays.py:2-9 plus the derived angles of BubbleImageCreator.py:163-165"""
+
+
+def final_rays(raytracer_output, n_rays, index_base=0):
+    """Restatement of python/BubbleImageCreator.py:134-165 (the loop as its MATLAB comments mean it: the numpy lines do not
+    run - `range(np.size(x,0,-1))`, `np.zeros(n, 10)`, `not array`, two-output np.isin).  Walk the scatter steps from the
+    last to the first; a ray id not found yet whose (positive) id is a member of that step's ray_index takes that step's
+    record, at the lowest row holding it (ismember).  Ray ids start at index_base.  Rays never found keep zeros.
+    cos_incident uses columns 1:3 of the incoming ray (the numpy `0:2` cannot broadcast)."""
+    fr = FinalRays()
+    fr.incoming_ray = np.zeros((n_rays, 10)); fr.intersection_point = np.zeros((n_rays, 3)); fr.surface_normal = np.zeros((n_rays, 3))
+    fr.ray_index = np.zeros(n_rays); fr.surface_index = np.zeros(n_rays)
+    found = np.zeros(n_rays, bool)
+    ids = np.arange(n_rays) + index_base
+    for n in range(len(raytracer_output) - 1, -1, -1):                       # :149
+        if found.all():
+            break                                                            # :150-151
+        ri = np.asarray(raytracer_output[n].ray_index).ravel()
+        first = {}
+        for row, v in enumerate(ri):                                         # ismember: lowest row
+            if v not in first:
+                first[v] = row
+        present = np.array([float(i) in first for i in ids], bool) if n_rays else np.zeros(0, bool)   # :153
+        these = ~found & present                                             # :154
+        found |= these                                                       # :156
+        rows = np.array([first[float(i)] for i in ids[these]], dtype=int)
+        fr.incoming_ray[these] = np.asarray(raytracer_output[n].incoming_ray)[rows]          # :157
+        fr.intersection_point[these] = np.asarray(raytracer_output[n].intersection_point)[rows]   # :158
+        fr.surface_normal[these] = np.asarray(raytracer_output[n].surface_normal)[rows]      # :159
+        fr.ray_index[these] = ri[rows]                                       # :160
+        fr.surface_index[these] = np.asarray(raytracer_output[n].surface_index).ravel()[rows]    # :161
+    fr.found = found
+    fr.cos_incident = -np.sum(fr.incoming_ray[:, 0:3] * fr.surface_normal, axis=1)   # :163
+    with np.errstate(invalid="ignore"):
+        fr.sin_incident = np.sqrt(1 - fr.cos_incident ** 2)                  # :164
+    fr.theta_incident = np.arccos(np.clip(fr.cos_incident, -1.0, 1.0))       # :165 (clamped: see ora_match_endpoints)
+    return fr
+
+
+def match_endpoints(cam, led, surfaces, max_dist=5.0, angle_den=2 * 10 * np.pi / 180, cam_den=2 * 45 * np.pi / 180, led_den=2 * 45 * np.pi / 180, dist_den=2 * 2 ** 2):
+    """ora_match_endpoints on two FinalRays: (pixel_intensity, led_cam, led_dist, led_add).  `surfaces` in the convention
+    of surface_index (sign ignored).  Rays never found (zeros, surface_index 0) only take part if 0 is listed - callers
+    mask them by setting surface_index to NaN first when the geometry is 0-based."""
+    L = lib()
+    n_cam, n_led = cam.intersection_point.shape[0], led.intersection_point.shape[0]
+    arr = lambda a: np.ascontiguousarray(a, float)  # noqa: E731
+    c_ip, c_ir, c_th, c_six = arr(cam.intersection_point), arr(cam.incoming_ray), arr(cam.theta_incident), arr(cam.surface_index)
+    l_ip, l_ir, l_th, l_six = arr(led.intersection_point), arr(led.incoming_ray), arr(led.theta_incident), arr(led.surface_index)
+    sf = np.ascontiguousarray(surfaces, np.int32)
+    pix = np.zeros(n_cam); lc = np.zeros(n_led, np.int64); ld = np.zeros(n_led); la = np.zeros(n_led)
+    L.ora_match_endpoints(_dp(c_ip), _dp(c_ir), _dp(c_th), _dp(c_six), C.c_int64(n_cam), _dp(l_ip), _dp(l_ir), _dp(l_th), _dp(l_six), C.c_int64(n_led),
+                          sf.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(sf.size), C.c_double(max_dist), C.c_double(angle_den), C.c_double(cam_den),
+                          C.c_double(led_den), C.c_double(dist_den), _dp(pix), lc.ctypes.data_as(C.POINTER(C.c_int64)), _dp(ld), _dp(la))
+    return pix, lc, ld, la

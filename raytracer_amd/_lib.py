@@ -11,7 +11,7 @@ FLAG_FULL_OUTPUT, FLAG_SINGLECHILD, FLAG_FINAL_ROWS = 1, 2, 4
 COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
 
 EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device",
-           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_record_sink", "rt_set_option", "rt_result_num_steps", "rt_result_table",
+           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_record_sink", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_table",
            "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_final", "rt_result_timing",
            "rt_result_timing_by_kernel", "rt_device_info")
 
@@ -29,6 +29,12 @@ class Camera(C.Structure):
                 ("position", C.c_double * 3), ("polref", C.c_double * 3), ("stokes", C.c_double * 4)]
 
 
+class MatchParams(C.Structure):
+    _fields_ = [("max_dist", C.c_double), ("angle_den", C.c_double), ("cam_incidence_den", C.c_double), ("led_incidence_den", C.c_double),
+                ("dist_den", C.c_double), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+MATCH_DEVICE_POINTERS = 1
 LENS_TYPES = {"tan": 0, "theta": 1, "sin": 2}
 RECORD_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                           C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64, C.c_int64)
@@ -59,6 +65,8 @@ def load():
     L.rt_trace_camera.argtypes = [C.c_void_p, P(Camera), P(Params)]
     L.rt_generate_camera_rays.argtypes = [C.c_void_p, P(Camera), C.c_int64, C.c_int64, P(C.c_double), P(C.c_double), P(C.c_int32)]
     L.rt_set_record_sink.argtypes = [C.c_void_p, RECORD_SINK, C.c_void_p]
+    L.rt_match_endpoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, P(C.c_int32), C.c_int32, P(MatchParams),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.rt_result_num_steps.argtypes = [C.c_void_p, P(C.c_int32)]
     L.rt_result_table.argtypes = [C.c_void_p, P(C.c_double)]

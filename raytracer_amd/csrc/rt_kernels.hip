@@ -1097,3 +1097,5 @@ extern "C" int rt_result_timing_by_kernel(rt_ctx* ctx, double ms[3], int32_t lau
     return 0;
 }
 extern "C" int rt_result_timing(rt_ctx* ctx, double* kernel_ms, int32_t* n_launches) { if (kernel_ms) *kernel_ms = ctx->kernel_ms; if (n_launches) *n_launches = ctx->n_launches; return 0; }
+
+#include "rt_match.hpp"

@@ -45,6 +45,8 @@ class ArBCSpecs(object):
         # camera, CreateArBCGeometry.m:135-146
         self.cam_x = 0; self.cam_y = 0; self.cam_z = 5; self.cam_f = .8; self.cam_barreld = 0; self.cam_lenstype = 'theta'
         self.cam_sensorsize = np.array([.1, .1]); self.cam_resolution = np.array([480, 640]); self.cam_pitch = 0; self.cam_yaw = 0; self.cam_roll = 0
+        # lights, python/geospecs.py:100-104 (see BubbleImageCreator.arbc_lights)
+        self.lights_number = 5; self.lights_height = -8.5; self.lights_radius = 7.5; self.lights_nrays = 100; self.lens_angle = (2 / 3) * np.pi
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown geospec %r" % k)
