@@ -593,6 +593,7 @@ struct rt_ctx {
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
     int level_steps = 24; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 16;
+    int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
 };
 
 static std::string g_init_err;
@@ -656,6 +657,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "hit_blocks_per_cu") ctx->hit_blocks_per_cu = (int)value;
     else if (k == "hit_split") ctx->hit_split = (int)value;
     else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
+    else if (k == "match_max_level") ctx->match_max_level = std::min(10, std::max(0, (int)value));
     else { ctx->err = "rt_set_option: unknown key " + k; return -1; }
     return 0;
 }

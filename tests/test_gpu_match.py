@@ -11,17 +11,38 @@ pytestmark = pytest.mark.gpu
 
 
 def _check(cam_rows, led_rows, surfaces, **kw):
+    """octree as deep as the density asks for, two levels at most, and the plain uniform grid: all equal to the oracle"""
     from raytracer_amd.BubbleImageCreator import match_leds_to_camera
-    pix, lc, ld, la = match_leds_to_camera(cam_rows, led_rows, surfaces, details=True, **kw)
+    from raytracer_amd.RayTracer2 import get_context
     okw = {}
     if "max_dist" in kw:
         okw["max_dist"] = kw["max_dist"]
     pix0, lc0, ld0, la0 = O.match_endpoints(M.final_rays_of(cam_rows), M.final_rays_of(led_rows), surfaces, **okw)
-    assert np.array_equal(lc, lc0)
-    assert np.array_equal(ld, ld0)
-    assert np.allclose(la, la0, rtol=1e-12, atol=0)
-    assert np.allclose(pix, pix0, rtol=1e-9, atol=1e-300)
+    c = get_context(0)
+    try:
+        for lev in (10, 2, 0):
+            c.set_option("match_max_level", lev)
+            pix, lc, ld, la = match_leds_to_camera(cam_rows, led_rows, surfaces, details=True, ctx=c, **kw)
+            assert np.array_equal(lc, lc0), lev
+            assert np.array_equal(ld, ld0), lev
+            assert np.allclose(la, la0, rtol=1e-12, atol=0), lev
+            assert np.allclose(pix, pix0, rtol=1e-9, atol=1e-300), lev
+    finally:
+        c.set_option("match_max_level", 10)
     return pix, lc
+
+
+def test_match_dense_clusters():
+    """many end points per coarse cell (the octree goes several levels deep), some LED rays far from every camera ray"""
+    rng = np.random.default_rng(21)
+    cam = M.cloud(20000, rng, [1, 2], extent=3.0)
+    cam[:, 2] = 0.1 * np.sin(cam[:, 0])                         # a thin sheet, as end points on a surface are
+    led = M.cloud(3000, rng, [1, 2], extent=9.0); led[:, 2] *= 0.05
+    _check(cam, led, [1, 2], max_dist=5.0)
+    _check(cam, led, [2], max_dist=0.7)
+    cam2 = M.cloud(6000, rng, [4], extent=0.01, lattice=0.001)  # everything within one leaf cell of the deepest level
+    led2 = M.cloud(500, rng, [4], extent=0.012, lattice=0.001)
+    _check(cam2, led2, [4], max_dist=5.0)
 
 
 @pytest.mark.parametrize("seed,n_cam,n_led,max_dist", [(1, 3000, 2000, 5.0), (2, 500, 4000, 1.5), (3, 4000, 300, 40.0), (4, 1, 50, 100.0)])
