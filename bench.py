@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--workload", default="sbc_full_mc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--host-inputs", action="store_true", help="hand the rays over as host arrays (N x 3, N x 10), as the Python boundary does: "
+                    "the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,6 +125,14 @@ def main():
     else:
         org = (C.c_double * 3)(*origin)
 
+    h_sp = h_rays = None
+    if a.host_inputs:
+        if cam is not None:
+            raise SystemExit("--host-inputs is for the point-source workloads")
+        h_sp = np.zeros((a.rays, 3)); h_rays = np.zeros((a.rays, 10))
+        dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        ctx._check(ctx.L.rt_generate_point_source(ctx.h, org, a.rays, C.c_uint64(a.seed), 0, dp(h_sp), dp(h_rays)))
+
     by_kernel = [[0.0, 0], [0.0, 0], [0.0, 0]]  # k_trace, k_level_hit, k_level_phys: ms, launches
     hit_units = [0]
 
@@ -130,6 +140,8 @@ def main():
         prm = ctx.params(kw["K"], flags, 0, kw["min_travel"], kw["thr"], kw["tir"], a.seed, (rank * (a.steps + a.warmup) + i) * a.rays)
         if cam is not None:
             ctx._check(ctx.L.rt_trace_camera(ctx.h, C.byref(cam), C.byref(prm)))
+        elif h_sp is not None:
+            ctx._check(ctx.L.rt_trace(ctx.h, dp(h_sp), dp(h_rays), a.rays, C.byref(prm)))
         else:
             ctx._check(ctx.L.rt_trace_point_source(ctx.h, org, a.rays, C.byref(prm)))
         live, scat = ctx.step_counts(kw["K"])
@@ -194,7 +206,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d-surface jar geometry, %s, MC single-child, K=%d, thr=%g, %d rays/step/GPU, full_output off"
-                                   % (a.workload, S, "point source" if cam is None else "camera rays generated on the device", kw["K"], kw["thr"][0], a.rays),
+                                   % (a.workload, S, ("point source" if h_sp is None else "point-source rays handed over as HOST arrays (PCIe-inclusive)") if cam is None
+                                      else "camera rays generated on the device", kw["K"], kw["thr"][0], a.rays),
                        "rays_per_step_per_gpu": a.rays, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
