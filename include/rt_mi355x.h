@@ -168,10 +168,12 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
 
 /* Tuning knobs (no reference counterpart): "workspace_gb" (device memory for records/queues, default 32),
  * "level_steps" / "level_min_rays" (single-child runs are traced step by step for at most that many steps and while
- * at least that many rays are live, the persistent kernel takes the rest; 24 / 32768), "hit_split", "frames" (0: the
+ * at least that many rays are live, the persistent kernel takes the rest; no cap / 32768), "defer_unified" (0: rays ending
+ * on UNIFIED surfaces are not given a physics launch of their own), "hit_split", "frames" (0: the
  * reference's formulas for every surface instead of the frame program), "refill_min" (idle lanes per wave that
  * trigger a refill of the persistent kernel, default 4), "blocks_per_cu" (0 = occupancy query), "nodice_chunk" (rays
- * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "release_workspace" (free the pooled device buffers). */
+ * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "match_max_level" (rt_match_endpoints: deepest level of
+ * the search tree, default 10), "release_workspace" (free the pooled device buffers). */
 int rt_set_option(rt_ctx* ctx, const char* key, double value);
 
 /* Record streaming (no reference counterpart: the reference keeps every rayInterfaces array in

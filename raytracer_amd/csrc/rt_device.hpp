@@ -49,7 +49,16 @@ RT_HD V3 cross(V3 a, V3 b) {
     return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
 }
 template <class Ptr> RT_HD V3 ld3(Ptr p) { return { p[0], p[1], p[2] }; }
-RT_HD V3 normalized_if(V3 a) { double n = dot(a, a); if (n > 0) { double s = 1.0 / sqrt(n); return s * a; } return a; }
+RT_HD V3 normalized_if(V3 a) {
+    // no FMA contraction here either: normalising d and -d at two places of the code must give exactly opposite vectors,
+    // whatever the compiler makes of the surrounding code (back-reflection: normal = -direction, cross() above)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const double n = a.x * a.x + a.y * a.y + a.z * a.z;
+    if (n > 0) { const double s = 1.0 / sqrt(n); return { s * a.x, s * a.y, s * a.z }; }
+    return a;
+}
 RT_HD int isgn(double x) { return (x > 0) - (x < 0); }
 
 struct Ray10 { V3 d, pol; double s0, s1, s2, s3; };
@@ -1126,7 +1135,7 @@ RT_HD void renorm(Ray10& t, double s0) { double f = s0 / t.s0; t.s0 *= f; t.s1 *
 // budget (occupancy) of the whole bounce kernel.  The generator travels by value; the caller re-aligns its stream to
 // the next Philox block afterwards (rng_align), so nothing has to come back but the ray.
 struct UnifiedOut { Ray10 r; uint32_t idx; };
-RT_COLD UnifiedOut unified(Rng g, Ray10 in, V3 nrm, double n1, double n2, double sig, double pdiff, double c1, double c2, double c3, int maxiter) {
+RT_HD UnifiedOut unified_body(Rng g, Ray10 in, V3 nrm, double n1, double n2, double sig, double pdiff, double c1, double c2, double c3, int maxiter) {
     Ray10 R = in;
     R.d = normalized_if(R.d);
     V3 N = normalized_if(nrm);
@@ -1183,6 +1192,9 @@ RT_COLD UnifiedOut unified(Rng g, Ray10 in, V3 nrm, double n1, double n2, double
         }
     }
     return UnifiedOut{ R, g.idx };
+}
+RT_COLD UnifiedOut unified(Rng g, Ray10 in, V3 nrm, double n1, double n2, double sig, double pdiff, double c1, double c2, double c3, int maxiter) {
+    return unified_body(g, in, nrm, n1, n2, sig, pdiff, c1, c2, c3, maxiter);
 }
 RT_HD void rng_align(Rng& g, uint32_t idx) { g.idx = (idx + 1u) & ~1u; } // continue with a fresh Philox block
 
@@ -1330,7 +1342,10 @@ struct LeanBounce {
     double bulk_abs, surf_abs, inc_intensity, s0_child; // s0_child: refracted_rays[:,6] after the dice
     V3 p; Ray10 child;
 };
-RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b) {
+// UNI = 1: the kernel pass that sees nothing but rays ending on UNIFIED surfaces carries the rough-surface loop in
+// line, with the register budget that needs; UNI = 2: the pass that has put those rays aside carries no UNIFIED code at
+// all; UNI = 0 (everywhere else): out of line.
+template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b) {
     Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
     b.scat = 0; b.surf_sc = 0; b.fa = 0; b.smix_next = 0; b.six_next = 0; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = 0;
@@ -1358,7 +1373,7 @@ RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, co
     if (rayl1 < INFINITY) l_bulk = -rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
     const bool surf_sc = h.l <= l_bulk;
     b.surf_sc = surf_sc;
-    const bool uni_sc = surf_sc && st == ST_UNIFIED, nor_sc = surf_sc && !uni_sc;
+    const bool uni_sc = UNI != 2 && surf_sc && st == ST_UNIFIED, nor_sc = surf_sc && !uni_sc;
     double l = h.l;
     if (!surf_sc) { b.six_next = 0; l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
     b.p = pn;
@@ -1394,12 +1409,19 @@ RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, co
         ch.s0 *= f; ch.s1 *= f; ch.s2 *= f; ch.s3 *= f;
     } else {
         Ray10 r;
-        if (uni_sc) { // :443-444
-            const double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
-            UnifiedOut u = unified(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
-            r = u.r; rng_align(g, u.idx);
-            r.s0 *= f; r.s1 *= f; r.s2 *= f; r.s3 *= f;
-        } else r = rayleigh(g, inc, G.lut, G.lut_prec); // :452-454
+        bool ray_sc = true;
+        if constexpr (UNI != 2) {
+            if (uni_sc) { // :443-444
+                const double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
+                UnifiedOut u;
+                if constexpr (UNI == 1) u = unified_body(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
+                else u = unified(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
+                r = u.r; rng_align(g, u.idx);
+                r.s0 *= f; r.s1 *= f; r.s2 *= f; r.s3 *= f;
+                ray_sc = false;
+            }
+        }
+        if (ray_sc) r = rayleigh(g, inc, G.lut, G.lut_prec); // :452-454
         tot = r.s0 + 0.0;
         const bool roll = rng_uniform(g) < (r.s0 / tot);
         if (roll) ch = r;

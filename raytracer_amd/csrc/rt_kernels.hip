@@ -79,6 +79,9 @@ struct KArgs {
     // of its rays, compacted, into the same range of the output queue (count -> seg_out[b]).  No counter is shared
     // between blocks: one atomic on one address per wave and step was what the physics kernel spent most of its time on.
     const uint32_t* seg_in; uint32_t* seg_out; int64_t seg_cap;
+    // rays that end on a UNIFIED surface are put aside by the first physics pass (their offsets within the segment,
+    // defer[b * seg_cap + j], j < defer_n[b]) and taken by a second launch in which every lane runs the rough-surface loop
+    uint32_t* defer; uint32_t* defer_n;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -394,6 +397,9 @@ template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_b
 #ifndef RT_PHYS_WAVES
 #define RT_PHYS_WAVES 3
 #endif
+#ifndef RT_UNI_WAVES
+#define RT_UNI_WAVES 2 /* the pass that runs the UNIFIED rough-surface loop in line */
+#endif
 // what the nearest-hit kernel needs, and nothing else (kernel arguments live in SGPRs)
 struct HitArgs {
     const double* in_d; const int32_t* in_m; int64_t in_stride, n_in;
@@ -451,8 +457,11 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
     }
 }
 
-template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_level_phys(const KArgs a) {
+// PASS 0: every ray of the segment.  PASS 1: rays ending on a UNIFIED surface are only listed (KArgs::defer).
+// PASS 2: the listed rays, children appended behind those of pass 1.  Passes 1 and 2 exist for CF == FLAG_SINGLE.
+template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS == 2 ? RT_UNI_WAVES : RT_PHYS_WAVES) k_level_phys(const KArgs a) {
     extern __shared__ double smem[];
+    if constexpr (PASS == 2) { if (a.defer_n[blockIdx.x] == 0) return; } // nothing put aside in this segment
     // LDS image: surface rows (per-lane gather of the winning surface) | this step's tally row | step counters
     double* s_surf = smem;
     double* s_tab = s_surf + a.S * ROW;
@@ -460,7 +469,8 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
     uint32_t* s_cnt = (uint32_t*)(s_tab + ntab);
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
-    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0u; // live, scattered, children
+    const uint32_t child0 = PASS == 2 ? a.seg_out[blockIdx.x] : 0u;
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred
     __syncthreads();
     Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr, (udptr)a.prog, a.nprog };
     const Prm P = a.P;
@@ -468,20 +478,28 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
     constexpr int BF = CF & FLAG_SINGLE;
     const int k = a.step;
     KArgs t = a; t.rows_lds = 1; // tally_add(): row 0 of the LDS image is step k
-    const int64_t seg0 = (int64_t)blockIdx.x * a.seg_cap, n = seg0 + (int64_t)a.seg_in[blockIdx.x];
+    const int64_t seg0 = (int64_t)blockIdx.x * a.seg_cap;
+    const int64_t n = seg0 + (int64_t)(PASS == 2 ? a.defer_n[blockIdx.x] : a.seg_in[blockIdx.x]);
     for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
-        const int64_t idx = base + lane_id();
+        int64_t idx = base + lane_id();
         if (idx < n) {
+            if constexpr (PASS == 2) idx = seg0 + (int64_t)a.defer[idx];
+            const int so = a.hit_so[idx];
+            if constexpr (PASS == 1) {
+                if (so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED) {
+                    a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
+                    continue;
+                }
+            }
             RayState q; load_queue_ray(a, idx, q);
             q.k = k;
             q.r.d = normalized_if(q.r.d);
             Hit h; h.l = a.hit_l[idx];
-            const int so = a.hit_so[idx];
             h.surf = so < 0 ? -1 : (so >> 2); h.orient = so < 0 ? 0 : (so & 3) - 1;
             atomicAdd(&s_cnt[0], 1u);
             if constexpr (CF == FLAG_SINGLE) { // tallies only: one child, built after the dice
                 LeanBounce b;
-                bounce_phys_single(G, P, q, h, b);
+                bounce_phys_single<PASS == 2 ? 1 : (PASS == 1 ? 2 : 0)>(G, P, q, h, b);
                 if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
                 else {
                     atomicAdd(&s_cnt[1], 1u);
@@ -529,7 +547,8 @@ template <int CF> __global__ void __launch_bounds__(BLOCK, RT_PHYS_WAVES) k_leve
         if (s_cnt[0]) atomicAdd(&a.n_live[k], (unsigned long long)s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&a.n_scat[k], (unsigned long long)s_cnt[1]);
         a.seg_out[blockIdx.x] = s_cnt[2];
-        if (s_cnt[2]) atomicAdd(a.tail, (unsigned long long)s_cnt[2]);
+        if (s_cnt[2] > child0) atomicAdd(a.tail, (unsigned long long)(s_cnt[2] - child0));
+        if constexpr (PASS == 1) a.defer_n[blockIdx.x] = s_cnt[3];
     }
 }
 
@@ -575,7 +594,7 @@ struct rt_ctx {
     double* d_cam = nullptr; // camera block of the last rt_trace_camera / rt_generate_camera_rays
     double* d_prog = nullptr; int nprog_frames = 0, nprog_generic = 0; // frame program, then the all-generic program
     bool use_frames = true, frames_have_generic = false;
-    bool has_rayleigh = false;
+    bool has_rayleigh = false, has_unified = false; bool defer_unified = true;
     int S = 0, n_atoms = 0, n_code = 0, lut_n = 0;
     // persistent small buffers
     unsigned long long* d_counters = nullptr; // head, tail, rec_count + overflow(int)
@@ -592,7 +611,7 @@ struct rt_ctx {
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 24; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 16;
+    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 16;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
 };
 
@@ -657,6 +676,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "hit_blocks_per_cu") ctx->hit_blocks_per_cu = (int)value;
     else if (k == "hit_split") ctx->hit_split = (int)value;
     else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
+    else if (k == "defer_unified") ctx->defer_unified = value != 0;
     else if (k == "match_max_level") ctx->match_max_level = std::min(10, std::max(0, (int)value));
     else { ctx->err = "rt_set_option: unknown key " + k; return -1; }
     return 0;
@@ -713,7 +733,8 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
     CK(hipMemcpy(ctx->d_surf, table, sizeof(double) * (size_t)n_surf * ROW, hipMemcpyHostToDevice));
     CK(hipMemcpy(ctx->d_recs, recs.data(), sizeof(double) * recs.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(ctx->d_smeta, smeta.data(), 4 * smeta.size(), hipMemcpyHostToDevice));
-    ctx->has_rayleigh = false;
+    ctx->has_rayleigh = false; ctx->has_unified = false;
+    for (int s = 0; s < n_surf; s++) if ((int)table[(size_t)s * ROW + 1] == ST_UNIFIED) ctx->has_unified = true;
     for (int s = 0; s < n_surf; s++) if (table[(size_t)s * ROW + 20] < INFINITY || table[(size_t)s * ROW + 21] < INFINITY) ctx->has_rayleigh = true;
     ctx->S = n_surf; ctx->n_atoms = n_atoms; ctx->n_code = n_code;
     return 0;
@@ -812,7 +833,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (wantfin) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (FIN * 8))));
         if (prm->follow_threshold[1] < 0) q_cap = chunk * K; // degenerate: reflected child followed as well
         if (level) { // two ray queues (ping-pong) + the hit of every live ray
-            const size_t per_ray = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12;
+            const size_t per_ray = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12 + 4; // + hit (12 B) + deferred-ray list (4 B)
             chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / per_ray)));
             q_cap = chunk + (int64_t)ctx->n_cu * 8; // segments round the capacity up
         }
@@ -823,9 +844,12 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     }
     if (full && rec_cap < chunk) { rec_cap = chunk; }
 
-    DevBuf b_hl, b_hso, b_seg;
+    DevBuf b_hl, b_hso, b_seg, b_defer;
     const int nseg_max = ctx->n_cu * 8;
-    if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 2 * (size_t)nseg_max)); }
+    // tally-only runs through a geometry with UNIFIED surfaces: those interactions get a launch of their own (k_level_phys PASS 1 + 2)
+    const bool defer = level && !out && ctx->has_unified && ctx->defer_unified;
+    if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 3 * (size_t)nseg_max)); }
+    if (defer) CK(dev_alloc(ctx, b_defer, 4 * (size_t)q_cap));
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
     Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
     if (q_cap > 0) { if (alloc_queue(ctx, q[0], b_q0d, b_q0i, b_q0m, q_cap)) return -1; if (alloc_queue(ctx, q[1], b_q1d, b_q1i, b_q1m, q_cap)) return -1; }
@@ -851,7 +875,9 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
     a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base;
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
-    void (*kphys)(const KArgs) = out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : k_level_phys<FLAG_SINGLE>;
+    void (*kphys)(const KArgs) = out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : ((defer || !ctx->has_unified) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
+    void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
+    a.defer = (uint32_t*)b_defer.p; a.defer_n = level ? (uint32_t*)b_seg.p + 2 * (size_t)nseg_max : nullptr;
     void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
     const bool prog_generic = !(ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2)) || ctx->frames_have_generic;
     void (*khit)(const HitArgs) = prog_generic ? k_level_hit<true> : k_level_hit<false>;
@@ -862,6 +888,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (level) {
         if (lds_phys > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
         CK(hipFuncSetAttribute((const void*)kphys, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
+        if (defer) CK(hipFuncSetAttribute((const void*)kphys2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
     }
     const int hit_bpc = ctx->hit_blocks_per_cu > 0 ? ctx->hit_blocks_per_cu : 4096, phys_bpc = ctx->phys_blocks_per_cu > 0 ? ctx->phys_blocks_per_cu : RT_PHYS_WAVES;
 
@@ -907,6 +934,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 hipLaunchKernelGGL(khit, dim3((unsigned)(nseg * ha.split)), dim3(BLOCK), lds_hit, ctx->stream, ha);
                 CK(hipEventRecord(ev1, ctx->stream));
                 hipLaunchKernelGGL(kphys, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
+                if (defer) hipLaunchKernelGGL(kphys2, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
                 CK(hipEventRecord(ev2, ctx->stream));
                 CK(hipGetLastError());
                 unsigned long long nxt = 0, cnt[4];
@@ -916,7 +944,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 float ms = 0;
                 CK(hipEventElapsedTime(&ms, ev0, ev1)); ctx->ms_kind[1] += ms; ctx->n_kind[1]++; ctx->kernel_ms += ms;
                 CK(hipEventElapsedTime(&ms, ev1, ev2)); ctx->ms_kind[2] += ms; ctx->n_kind[2]++; ctx->kernel_ms += ms;
-                ctx->n_launches += 2;
+                ctx->n_launches += defer ? 3 : 2;
                 int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
                 if (ovf) { ctx->err = "rt_trace: record buffer overflow (raise workspace)"; rc = -3; break; }
                 live = (int64_t)nxt;

@@ -42,6 +42,7 @@ class ArBCSpecs(object):
         self.target_rayleigh = np.inf; self.target_abslength = np.inf
         self.reflector_type = "normal"; self.reflector_absorption = 1.0; self.reflector_unifiedparams = [0, 1, 0, 1, 0]
         self.reflector_n_inside = None
+        self.reflector_all = False   # True: the strip cone, top cone and bottom cone get the reflector's optics too
         # camera, CreateArBCGeometry.m:135-146
         self.cam_x = 0; self.cam_y = 0; self.cam_z = 5; self.cam_f = .8; self.cam_barreld = 0; self.cam_lenstype = 'theta'
         self.cam_sensorsize = np.array([.1, .1]); self.cam_resolution = np.array([480, 640]); self.cam_pitch = 0; self.cam_yaw = 0; self.cam_roll = 0
@@ -186,10 +187,12 @@ def create_arbc_geometry(geospecs=None):
     sl.append(_mk('reflector/diffuser', 'cylinder', [z0, zax, g.rd_rad], zband(g.rd_bot, g.rd_top, hi_incl=True), n_refl_in, nh, **rkw))
     sl.append(_mk('reflector/diffuser cone', 'quadsurface', list(rd_cone), zband(g.rd_top, g.rdcone_top), n_refl_in, nh, **rkw))
     nr2 = g.vp_nip_rad ** 2
+    ckw = rkw if g.reflector_all else dict(absorption=1)   # black in the MATLAB file
+    n_cone = n_refl_in if g.reflector_all else nh          # the reflector's far side: away from the jar
     sl.append(_mk('reflector/diffuser strip cone', 'quadsurface', list(rd_stcone),
-                  lambda p: np.reshape((p[:, 2, :] > g.rdcone_top) & (p[:, 2, :] < g.rdtopcone_bot) & (off_axis2(p) > nr2), (p.shape[0], -1)), nh, nh, absorption=1))
-    sl.append(_mk('reflector/diffuser topcone', 'quadsurface', list(rd_topcone), zband(g.rdtopcone_bot, g.rdtopcone_apex), nh, nh, absorption=1))
-    sl.append(_mk('reflector/diffuser botcone', 'quadsurface', list(rd_botcone), zband(g.rdbotcone_bot, g.rdbotcone_apex), nh, nh, absorption=1))
+                  lambda p: np.reshape((p[:, 2, :] > g.rdcone_top) & (p[:, 2, :] < g.rdtopcone_bot) & (off_axis2(p) > nr2), (p.shape[0], -1)), n_cone, nh, **ckw))
+    sl.append(_mk('reflector/diffuser topcone', 'quadsurface', list(rd_topcone), zband(g.rdtopcone_bot, g.rdtopcone_apex), n_cone, nh, **ckw))
+    sl.append(_mk('reflector/diffuser botcone', 'quadsurface', list(rd_botcone), zband(g.rdbotcone_bot, g.rdbotcone_apex), nh, n_cone, **ckw))
     sl.append(_mk('PV - cylinder outer wall', 'cylinder', [z0, zax, g.pv_rad], zband(g.pv_bot, g.pv_top), 1, nw, absorption=1))
     sl.append(_mk('PV - cylinder inner wall', 'cylinder', [z0, zax, g.pv_rad - g.pv_thick], zband(g.pv_bot, g.pv_top), nw, nh, absorption=1))
     fr2 = g.vp_flange_rad ** 2
@@ -252,8 +255,13 @@ def create_sbc_geometry(geospecs=None):
     return sl
 
 
-def sbc_full_mc_specs():
+def sbc_full_mc_specs(black_cones=False):
     """jar geometry with Rayleigh/absorption lengths of CreateSBCGeometry.m:40-41 in the target
-    fluid and a reflective (UNIFIED, rough dielectric-on-conductor) reflector/diffuser instead of the black one."""
+    fluid and reflective (UNIFIED, rough conductor, 10 % absorption) reflector/diffuser surfaces instead of the black
+    ones: the cylinder, its cone and the cones around the jar.  In single-child mode a reflector hit scales the ray's
+    intensity by 0.9 instead of ending it, so light keeps bouncing between jar and reflector until the intensity
+    threshold or max_scatters ends it (about 87 interactions per ray at K = 100, threshold 1e-4).
+    black_cones=True leaves the cones black as in the MATLAB file: nearly every ray ends on the top cone after 3-4
+    interactions (the workload of the builds r1a-r1f in DESIGN.md)."""
     return ArBCSpecs(target_rayleigh=29.0, target_abslength=300.0, reflector_type="unified", reflector_absorption=0.1,
-                     reflector_unifiedparams=[0.1, 0.0, 0.3, 0.2, 0.05], reflector_n_inside=np.inf)
+                     reflector_unifiedparams=[0.1, 0.0, 0.3, 0.2, 0.05], reflector_n_inside=np.inf, reflector_all=not black_cones)

@@ -33,11 +33,15 @@ def test_mixed_geometry_nodice_tir_positive_vs_oracle():
     compare_results(ref, got, growth=3.0)
 
 
-def test_arbc_geometry_dice_vs_oracle():
+@pytest.mark.parametrize("black_cones,K", [(True, 30), (False, 6)])
+def test_arbc_geometry_dice_vs_oracle(black_cones, K):
+    """ray-by-ray against the oracle.  With the reflective cones light bounces on for all K steps and last-bit differences
+    grow by a factor of a few per bounce (a billiard), so the record-level comparison stops after 6 steps there; the
+    long chains are compared as distributions in test_gpu_level.py::test_tally_only_runs_take_the_lean_step."""
     from raytracer_amd import geometries as G
-    sl = G.create_arbc_geometry(G.sbc_full_mc_specs())
+    sl = G.create_arbc_geometry(G.sbc_full_mc_specs(black_cones=black_cones))
     sp, rays = cases.isotropic_rays(20000, 3, origin=(0, 0, 10))
-    args = (30, [1e-6], 1e-4, -1, True, True, False)
+    args = (K, [1e-6], 1e-4, -1, True, True, False)
     got = gpu(sp, rays.copy(), sl, *args, compat="matlab", seed=11)
     ref = O.trace(sp, rays.copy(), sl, *args, compat="matlab", seed=11)
     compare_results(ref, got, growth=3.0)
@@ -81,7 +85,7 @@ def test_point_source_generation_and_trace():
     from raytracer_amd import _lib
     from raytracer_amd.RayTracer2 import Context
     from raytracer_amd import geometries as G, table as T
-    sl = G.create_arbc_geometry(G.sbc_full_mc_specs())
+    sl = G.create_arbc_geometry(G.sbc_full_mc_specs(black_cones=True))   # short chains: comparable to rounding (see above)
     prog = T.compile_surfaces(sl)
     c = Context(0); c.set_program(*prog)
     n = 50000; org = (C.c_double * 3)(0, 0, 10)
