@@ -1198,6 +1198,158 @@ RT_COLD UnifiedOut unified(Rng g, Ray10 in, V3 nrm, double n1, double n2, double
 }
 RT_HD void rng_align(Rng& g, uint32_t idx) { g.idx = (idx + 1u) & ~1u; } // continue with a fresh Philox block
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- the same model for a whole wave (k_level_phys PASS 2: every lane holds a ray that ended on a UNIFIED surface)
+// The rejection loop of the facet normal (UnifiedReflectorModel.m:278-306) accepts about one draw in five at small
+// sigma_alpha, and a wave waits for its unluckiest ray.  The generator is counter-based, so try number j of a ray can
+// be evaluated before tries 0..j-1 are known to fail: the rays still drawing are spread over the 64 lanes, 64 / (rays
+// left) tries each, and every ray keeps the first of its tries that passes - the same normal, the same number of
+// uniforms consumed as the ray-by-ray loop (the oracle's).  All 64 lanes must call (EXEC full); `need` marks the rays.
+__device__ __forceinline__ double rng_uniform_at(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t step, uint32_t k0, uint32_t k1, uint32_t i) {
+    uint32_t o0, o1, o2, o3;
+    philox(c0, c1, c2, (step << 20) | ((i >> 1) & 0xFFFFFu), k0, k1, o0, o1, o2, o3);
+    const uint32_t a = (i & 1u) ? o2 : o0, b = (i & 1u) ? o3 : o1;
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ void rng_seek(Rng& g, uint32_t idx) { // continue the stream at uniform number idx
+    g.idx = idx;
+    if (idx & 1u) philox(g.c0, g.c1, g.c2, (g.step << 20) | ((idx >> 1) & 0xFFFFFu), g.k0, g.k1, g.o0, g.o1, g.o2, g.o3);
+}
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl((int)b, src), hi = __shfl((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ V3 shfl_v3(V3 v, int src) { return V3{ shfl_d(v.x, src), shfl_d(v.y, src), shfl_d(v.z, src) }; }
+
+__device__ __forceinline__ V3 facet_normal_wave(bool need, Rng& g, V3 indir, V3 sn, V3 sx, V3 sy, double sig, int maxiter) {
+    V3 f = sn;
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long pending = __ballot(need && sig != 0 && maxiter > 0);
+    int it = 0;                      // tries of my ray that are known to have failed
+    const uint32_t idx0 = g.idx;
+    while (pending) {
+        const int np = __popcll(pending);
+        int c = 1; while (2 * c * np <= 64) c *= 2;                    // tries per ray this round
+        const int rank = __popcll(pending & ((1ull << lane) - 1ull));  // my ray's place among the rays still drawing
+        const bool mine = (pending >> lane) & 1ull;
+        // rank -> lane: every drawing lane sends its number to the lane of its rank
+        const int r2l = __builtin_amdgcn_ds_permute((mine ? rank : 63) << 2, mine ? lane : 0); // idle lanes all write to lane 63, which no rank < np <= 63 reads unless np == 64 (then nobody is idle)
+        const int s = lane / c, j = lane % c;
+        const bool work = s < np;
+        const int src = __shfl(r2l, work ? s : 0);
+        // the ray whose try this lane evaluates
+        const V3 rd = shfl_v3(indir, src), rn = shfl_v3(sn, src), rx = shfl_v3(sx, src), ry = shfl_v3(sy, src);
+        const double rs = shfl_d(sig, src);
+        const uint32_t r0 = (uint32_t)__shfl((int)g.c0, src), r1 = (uint32_t)__shfl((int)g.c1, src), r2 = (uint32_t)__shfl((int)g.c2, src), rstep = (uint32_t)__shfl((int)g.step, src);
+        const uint32_t ridx = (uint32_t)__shfl((int)idx0, src);
+        const int rit = __shfl(it, src);
+        const int tr = rit + j;                                        // number of the try
+        const uint32_t b = ridx + 4u * (uint32_t)tr;
+        const double u1 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b), u2 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b + 1u);
+        const double u3 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b + 2u), u4 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b + 3u);
+        const double th = fabs(rs * (sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2)));
+        double st, ct; sincos(th, &st, &ct);
+        const bool out_of_range = th >= 0.5 * 3.14159265358979323846;
+        const double fmx = rs * 4 < 1 ? rs * 4 : 1;
+        const bool fail_jac = u3 * fmx > st;
+        double sp, cp; sincos(TWO_PI * u4, &sp, &cp);
+        const V3 cand = ct * rn + (st * cp) * rx + (st * sp) * ry;
+        const bool wrong = dot(rd, cand) >= 0;
+        const bool last = tr == maxiter - 1;                           // the loop ends with this try whatever it gives
+        const bool ok = work && tr < maxiter && (last || !(out_of_range || fail_jac || wrong));
+        const unsigned long long okm = __ballot(ok);
+        // back at the rays: the first good try of my group, if any
+        const unsigned long long grp = (c == 64 ? okm : (okm >> (rank * c)) & ((1ull << c) - 1ull));
+        const bool hit = mine && grp != 0;
+        const int fj = hit ? __ffsll((long long)grp) - 1 : 0;
+        const V3 got = shfl_v3(cand, mine ? rank * c + fj : lane);
+        if (hit) { f = got; it += fj + 1; }
+        else if (mine) it += c;
+        pending &= ~__ballot(hit);
+    }
+    if (it > 0) rng_seek(g, idx0 + 4u * (uint32_t)it);
+    return f;
+}
+
+// unified_body() as a state machine in which every pass of the wave does at most one pass of the reference's inner
+// loop per ray, so that the facet normals of all rays that need one are drawn together.
+__device__ __forceinline__ UnifiedOut unified_wave(bool need, Rng g, Ray10 in, V3 nrm, double n1, double n2, double sig, double pdiff, double c1, double c2, double c3, int maxiter) {
+    Ray10 R = in;
+    R.d = normalized_if(R.d);
+    V3 N = normalized_if(nrm);
+    R.pol = R.pol - dot(R.pol, R.d) * R.d;
+    R.pol = normalized_if(R.pol);
+    V3 md = -R.d;
+    bool scattering = need && dot(md, N) > 0;
+    V3 sx = cross(md, N);
+    double sin_i = sqrt(dot(sx, sx));
+    if (sin_i > 0) sx = (1.0 / sin_i) * sx;
+    else {
+        V3 t = cross(V3{ 1, 0, 0 }, N);
+        if (!(dot(t, t) > 0)) t = cross(V3{ 0, 1, 0 }, N);
+        sx = (1.0 / sqrt(dot(t, t))) * t;
+    }
+    V3 sy = cross(N, sx);
+    bool insurface = false, crossing = false, second = false;
+    int guard = 0, guard2 = 0;
+    V3 nuse = N;
+    bool inner = false;              // inside the reference's `while crossing` loop
+    for (;;) {
+        // per ray: walk the loop heads until the next pass of the inner loop (or the end)
+        bool run = false;
+        if (need) {
+            for (int hop = 0; hop < 3; hop++) {
+                if (inner) {
+                    if (crossing && guard2++ < 2 * maxiter) { run = true; break; }
+                    inner = false;
+                    scattering = scattering && insurface;
+                    if (scattering) { // .m:259-267: Lambertian re-emission from inside the surface material
+                        R.d = lambert_dir(g, -N, sx, sy);
+                        R.s1 = R.s2 = R.s3 = 0; R.s0 *= pdiff;
+                        V3 t = cross(V3{ 1, 0, 0 }, R.d);
+                        if (dot(t, t) <= 0) t = cross(V3{ 0, 1, 0 }, R.d);
+                        R.pol = (1.0 / sqrt(dot(t, t))) * t;
+                    }
+                }
+                if (!(scattering && guard++ < maxiter)) { need = false; break; }
+                inner = true; crossing = true; second = false; nuse = N; guard2 = 0;
+            }
+        }
+        if (!__ballot(run)) break;
+        const V3 fn = facet_normal_wave(run && !second, g, R.d, N, sx, sy, sig, maxiter);
+        if (run) {
+            if (!second) nuse = fn;
+            FresnelCore fc; fresnel_core(R, nuse, n1, n2, fc);
+            const double s0_in = R.s0;
+            if (second) { fresnel_reflected(fc, R); renorm(R, s0_in); crossing = false; second = false; }
+            else {
+                double t_s0 = fresnel_refr_s0(fc), r_s0 = fresnel_refl_s0(fc);
+                bool reflect_here = rng_uniform(g) > (t_s0 / (t_s0 + r_s0));
+                if (!reflect_here) {
+                    fresnel_refracted(fc, -1.0, R); renorm(R, s0_in);
+                    N = -N;
+                    double t = n1; n1 = n2; n2 = t;
+                    insurface = !insurface;
+                    crossing = dot(R.d, N) <= 0;
+                } else {
+                    double roll = rng_uniform(g);
+                    if (roll < c1) { fresnel_reflected(fc, R); renorm(R, s0_in); crossing = dot(R.d, N) <= 0; }
+                    else {
+                        if (roll < c2) nuse = N;
+                        else if (roll < c3) nuse = -R.d;
+                        else { V3 od = lambert_dir(g, N, sx, sy); V3 t = od - R.d; nuse = (1.0 / sqrt(dot(t, t))) * t; }
+                        second = true;
+                    }
+                }
+            }
+        }
+    }
+    return UnifiedOut{ R, g.idx };
+}
+#endif
+
+
 // ---------------------------------------------------------------------------------------------- Rayleigh
 // MATLAB/Physics/RayleighScattering.m:62-148; lut = rayleigh_azimuth (:55-60), prec = azimuth_precision
 RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
@@ -1345,7 +1497,7 @@ struct LeanBounce {
 // UNI = 1: the kernel pass that sees nothing but rays ending on UNIFIED surfaces carries the rough-surface loop in
 // line, with the register budget that needs; UNI = 2: the pass that has put those rays aside carries no UNIFIED code at
 // all; UNI = 0 (everywhere else): out of line.
-template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b) {
+template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b, bool act = true) {
     Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
     b.scat = 0; b.surf_sc = 0; b.fa = 0; b.smix_next = 0; b.six_next = 0; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = 0;
@@ -1384,6 +1536,13 @@ template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P
     // the child that survives the dice, before the rescaling: chosen; its intensity and the sum of both
     Ray10 ch = inc; ch.s0 = ch.s1 = ch.s2 = ch.s3 = 0;
     double tot = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    UnifiedOut uw;
+    if constexpr (UNI == 1) { // all 64 lanes are here (see k_level_phys PASS 2); those with uni_sc are the rays
+        const double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
+        uw = unified_wave(uni_sc && act, g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
+    }
+#endif
     if (nor_sc) { // :438-439
         FresnelCore c; fresnel_core(inc, sopt, n1, n2, c);
         V3 ny; const bool goodcut = fresnel_yaxis(c, ny);
@@ -1414,8 +1573,13 @@ template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P
             if (uni_sc) { // :443-444
                 const double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
                 UnifiedOut u;
-                if constexpr (UNI == 1) u = unified_body(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
-                else u = unified(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
+                if constexpr (UNI == 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    u = uw;
+#else
+                    u = unified_body(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
+#endif
+                } else u = unified(g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
                 r = u.r; rng_align(g, u.idx);
                 r.s0 *= f; r.s1 *= f; r.s2 *= f; r.s3 *= f;
                 ray_sc = false;

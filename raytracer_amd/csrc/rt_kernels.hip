@@ -482,7 +482,11 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     const int64_t n = seg0 + (int64_t)(PASS == 2 ? a.defer_n[blockIdx.x] : a.seg_in[blockIdx.x]);
     for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
         int64_t idx = base + lane_id();
-        if (idx < n) {
+        // PASS 2: the wave works together on the rough-surface loop (unified_wave), so all 64 lanes go through the step;
+        // those behind the end of the list repeat its last ray and leave no trace
+        const bool act = idx < n;
+        if constexpr (PASS == 2) { if (!act) idx = n - 1; }
+        if (act || PASS == 2) {
             if constexpr (PASS == 2) idx = seg0 + (int64_t)a.defer[idx];
             const int so = a.hit_so[idx];
             if constexpr (PASS == 1) {
@@ -496,11 +500,12 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
             q.r.d = normalized_if(q.r.d);
             Hit h; h.l = a.hit_l[idx];
             h.surf = so < 0 ? -1 : (so >> 2); h.orient = so < 0 ? 0 : (so & 3) - 1;
-            atomicAdd(&s_cnt[0], 1u);
+            if (act) atomicAdd(&s_cnt[0], 1u);
             if constexpr (CF == FLAG_SINGLE) { // tallies only: one child, built after the dice
                 LeanBounce b;
-                bounce_phys_single<PASS == 2 ? 1 : (PASS == 1 ? 2 : 0)>(G, P, q, h, b);
-                if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
+                bounce_phys_single<PASS == 2 ? 1 : (PASS == 1 ? 2 : 0)>(G, P, q, h, b, act);
+                if (!act) {}
+                else if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
                 else {
                     atomicAdd(&s_cnt[1], 1u);
                     if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);

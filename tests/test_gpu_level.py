@@ -112,3 +112,31 @@ def test_record_streaming_npz_shards(tmp_path):
             o1 = np.lexsort((np.abs(got_idx),)); o2 = np.lexsort((np.abs(ri.ray_index),))
             got_l = np.concatenate([z["k%d_distance_traveled" % k] for z in shards if "k%d_distance_traveled" % k in z.files])
             assert np.array_equal(got_idx[o1], ri.ray_index[o2]) and np.allclose(got_l[o1], ri.distance_traveled[o2], rtol=1e-8, atol=1e-8)  # the chunks take the persistent kernel, the whole run the level kernels
+
+
+@pytest.mark.parametrize("params,n_in,n_med", [((.2, .8, .2, .3, .1), 1.5, 1.0), ((.05, .5, .3, .2, .05), np.inf, 1.5), ((0, 0, .25, .5, .1), np.inf, 1.5),
+                                               ((.6, .3, .5, .1, .1), 1.3, 1.5)])
+def test_unified_rays_get_their_own_launch(params, n_in, n_med):
+    """tally-only runs put the rays that end on UNIFIED surfaces aside and give them a launch in which the whole wave
+    draws facet normals together (unified_wave): same uniforms consumed, same tallies as the ray-by-ray loop - with the
+    separate launch, without it, and in the oracle (two interactions per ray: nothing for rounding to grow on)."""
+    from raytracer_amd.RayTracer2 import RayTracer2, get_context
+    n = 70001                                                  # not a multiple of anything: lists end inside a wave
+    sp, rays = cases.unifiedtest_rays(n)
+    rng = np.random.default_rng(4)
+    rays[:, 0:3] += 0.3 * rng.normal(size=(n, 3)); rays[:, 3:6] = rng.normal(size=(n, 3)); rays[:, 7] = 0.4; rays[:, 8] = -0.2; rays[:, 9] = 0.1
+    sl = cases.unifiedtest(params=params, n_panel_in=n_in, n_med=n_med)
+    ref = O.trace(sp, rays.copy(), sl, 10, 1e-9, 0, -1, False, True, False, seed=8, compat="matlab")
+    c = get_context(0)
+    try:
+        tabs = []
+        for d in (1, 0):
+            c.set_option("defer_unified", d); c.set_option("level_min_rays", 0)
+            tabs.append(RayTracer2(sp, rays.copy(), sl, 10, 1e-9, 0, -1, False, True, False, seed=8, compat="matlab")[1])
+            live, scat = c.step_counts(10)
+            assert np.array_equal(scat, ref.n_scat) and np.array_equal(live, ref.n_live)
+    finally:
+        c.set_option("defer_unified", 1); c.set_option("level_min_rays", 1 << 15)
+    assert tabs[0].shape == ref.absorption_table.shape
+    assert np.allclose(tabs[0], ref.absorption_table, rtol=1e-10, atol=1e-9)
+    assert np.allclose(tabs[1], ref.absorption_table, rtol=1e-10, atol=1e-9)
