@@ -82,6 +82,7 @@ struct KArgs {
     // rays that end on a UNIFIED surface are put aside by the first physics pass (their offsets within the segment,
     // defer[b * seg_cap + j], j < defer_n[b]) and taken by a second launch in which every lane runs the rough-surface loop
     uint32_t* defer; uint32_t* defer_n;
+    uint32_t* dense;        // pass 1: the other rays of the segment, listed the same way, so that its waves are full
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -470,7 +471,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
     const uint32_t child0 = PASS == 2 ? a.seg_out[blockIdx.x] : 0u;
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred, dense
     __syncthreads();
     Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr, (udptr)a.prog, a.nprog };
     const Prm P = a.P;
@@ -479,7 +480,21 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     const int k = a.step;
     KArgs t = a; t.rows_lds = 1; // tally_add(): row 0 of the LDS image is step k
     const int64_t seg0 = (int64_t)blockIdx.x * a.seg_cap;
-    const int64_t n = seg0 + (int64_t)(PASS == 2 ? a.defer_n[blockIdx.x] : a.seg_in[blockIdx.x]);
+    int64_t n = seg0 + (int64_t)(PASS == 2 ? a.defer_n[blockIdx.x] : a.seg_in[blockIdx.x]);
+    const bool listed = PASS == 2 || (PASS == 1 && a.defer != nullptr);
+    if (PASS == 1 && listed) { // sort the segment's rays into the two lists; this launch then takes the dense one
+        for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
+            const int64_t idx = base + lane_id();
+            if (idx < n) {
+                const int so = a.hit_so[idx];
+                if (so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED) a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
+                else a.dense[seg0 + (int64_t)wave_alloc_lds(&s_cnt[4])] = (uint32_t)(idx - seg0);
+            }
+        }
+        __syncthreads();
+        n = seg0 + (int64_t)s_cnt[4];
+    }
+    const uint32_t* list = PASS == 2 ? a.defer : a.dense;
     for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
         int64_t idx = base + lane_id();
         // PASS 2: the wave works together on the rough-surface loop (unified_wave), so all 64 lanes go through the step;
@@ -487,14 +502,8 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
         const bool act = idx < n;
         if constexpr (PASS == 2) { if (!act) idx = n - 1; }
         if (act || PASS == 2) {
-            if constexpr (PASS == 2) idx = seg0 + (int64_t)a.defer[idx];
+            if (listed) idx = seg0 + (int64_t)list[idx];
             const int so = a.hit_so[idx];
-            if constexpr (PASS == 1) {
-                if (so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED) {
-                    a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
-                    continue;
-                }
-            }
             RayState q; load_queue_ray(a, idx, q);
             q.k = k;
             q.r.d = normalized_if(q.r.d);
@@ -838,7 +847,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (wantfin) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (FIN * 8))));
         if (prm->follow_threshold[1] < 0) q_cap = chunk * K; // degenerate: reflected child followed as well
         if (level) { // two ray queues (ping-pong) + the hit of every live ray
-            const size_t per_ray = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12 + 4; // + hit (12 B) + deferred-ray list (4 B)
+            const size_t per_ray = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12 + 8; // + hit (12 B) + the two ray lists of the physics launches (4 B each)
             chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / per_ray)));
             q_cap = chunk + (int64_t)ctx->n_cu * 8; // segments round the capacity up
         }
@@ -854,7 +863,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     // tally-only runs through a geometry with UNIFIED surfaces: those interactions get a launch of their own (k_level_phys PASS 1 + 2)
     const bool defer = level && !out && ctx->has_unified && ctx->defer_unified;
     if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 3 * (size_t)nseg_max)); }
-    if (defer) CK(dev_alloc(ctx, b_defer, 4 * (size_t)q_cap));
+    if (defer) CK(dev_alloc(ctx, b_defer, 2 * 4 * (size_t)q_cap));
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
     Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
     if (q_cap > 0) { if (alloc_queue(ctx, q[0], b_q0d, b_q0i, b_q0m, q_cap)) return -1; if (alloc_queue(ctx, q[1], b_q1d, b_q1i, b_q1m, q_cap)) return -1; }
@@ -882,14 +891,14 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
     void (*kphys)(const KArgs) = out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : ((defer || !ctx->has_unified) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
     void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
-    a.defer = (uint32_t*)b_defer.p; a.defer_n = level ? (uint32_t*)b_seg.p + 2 * (size_t)nseg_max : nullptr;
+    a.defer = (uint32_t*)b_defer.p; a.dense = defer ? (uint32_t*)b_defer.p + (size_t)q_cap : nullptr; a.defer_n = level ? (uint32_t*)b_seg.p + 2 * (size_t)nseg_max : nullptr;
     void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
     const bool prog_generic = !(ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2)) || ctx->frames_have_generic;
     void (*khit)(const HitArgs) = prog_generic ? k_level_hit<true> : k_level_hit<false>;
     HitArgs ha; memset(&ha, 0, sizeof ha);
     ha.prog = a.prog; ha.nprog = a.nprog; ha.recs = ctx->d_recs; ha.surf = ctx->d_surf; ha.smeta = ctx->d_smeta; ha.S = S;
     ha.min_travel = a.P.min_travel; ha.base = a.P.base; ha.compat = a.P.compat; ha.hit_l = (double*)b_hl.p; ha.hit_so = (int32_t*)b_hso.p;
-    const size_t lds_hit = (size_t)TQ_DOUBLES * 8, lds_phys = (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 16;
+    const size_t lds_hit = (size_t)TQ_DOUBLES * 8, lds_phys = (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 32;
     if (level) {
         if (lds_phys > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
         CK(hipFuncSetAttribute((const void*)kphys, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
