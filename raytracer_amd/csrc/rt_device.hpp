@@ -1246,8 +1246,15 @@ __device__ __forceinline__ V3 facet_normal_wave(bool need, Rng& g, V3 indir, V3 
         const int rit = __shfl(it, src);
         const int tr = rit + j;                                        // number of the try
         const uint32_t b = ridx + 4u * (uint32_t)tr;
-        const double u1 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b), u2 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b + 1u);
-        const double u3 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b + 2u), u4 = rng_uniform_at(r0, r1, r2, rstep, g.k0, g.k1, b + 3u);
+        // uniforms b .. b+3 of that ray's stream: two Philox blocks, a third if the stream stands at an odd uniform
+        uint32_t p0, p1, p2, p3, q0, q1, q2, q3, w0 = 0, w1 = 0, w2, w3;
+        const uint32_t blk = b >> 1, odd = b & 1u;
+        philox(r0, r1, r2, (rstep << 20) | (blk & 0xFFFFFu), g.k0, g.k1, p0, p1, p2, p3);
+        philox(r0, r1, r2, (rstep << 20) | ((blk + 1u) & 0xFFFFFu), g.k0, g.k1, q0, q1, q2, q3);
+        if (__ballot(odd != 0)) philox(r0, r1, r2, (rstep << 20) | ((blk + 2u) & 0xFFFFFu), g.k0, g.k1, w0, w1, w2, w3);
+        auto u53 = [](uint32_t a, uint32_t c) { return ((double)(a >> 5) * 67108864.0 + (double)(c >> 6)) * (1.0 / 9007199254740992.0); };
+        const double u1 = odd ? u53(p2, p3) : u53(p0, p1), u2 = odd ? u53(q0, q1) : u53(p2, p3);
+        const double u3 = odd ? u53(q2, q3) : u53(q0, q1), u4 = odd ? u53(w0, w1) : u53(q2, q3);
         const double th = fabs(rs * (sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2)));
         double st, ct; sincos(th, &st, &ct);
         const bool out_of_range = th >= 0.5 * 3.14159265358979323846;
