@@ -79,6 +79,7 @@ struct KArgs {
     // of its rays, compacted, into the same range of the output queue (count -> seg_out[b]).  No counter is shared
     // between blocks: one atomic on one address per wave and step was what the physics kernel spent most of its time on.
     const uint32_t* seg_in; uint32_t* seg_out; int64_t seg_cap;
+    int64_t seg_fill;       // k_level_init: rays per segment at the start (== seg_cap unless rays split and segments need room to grow)
     // rays that end on a UNIFIED surface are put aside by the first physics pass (their offsets within the segment,
     // defer[b * seg_cap + j], j < defer_n[b]) and taken by a second launch in which every lane runs the rough-surface loop
     uint32_t* defer; uint32_t* defer_n;
@@ -417,8 +418,9 @@ template <int CF> __global__ void __launch_bounds__(BLOCK) k_level_init(const KA
     const bool wantfin = (CF & FLAG_FINAL) && (a.P.flags & FLAG_FINAL);
     RayState q; load_ray(a, idx, q, wantfin);
     q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
-    store_ray(a.out, idx, q);
-    if (idx % a.seg_cap == 0) a.seg_out[idx / a.seg_cap] = (uint32_t)(a.n_in - idx < a.seg_cap ? a.n_in - idx : a.seg_cap);
+    const int64_t sg = idx / a.seg_fill, off = idx % a.seg_fill;
+    store_ray(a.out, sg * a.seg_cap + off, q);
+    if (off == 0) a.seg_out[sg] = (uint32_t)(a.n_in - idx < a.seg_fill ? a.n_in - idx : a.seg_fill);
 }
 // segments -> dense queue (hand-over to the persistent kernel)
 __global__ void __launch_bounds__(BLOCK) k_level_compact(const KArgs a) {
@@ -546,9 +548,18 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
                     }
                     if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + (q.ray_id - a.slot_base) * FIN);
                     if (k + 1 < P.K && (b.fa || b.fb)) { // single child: exactly one of fa, fb can be set
+                        if constexpr (BF == 0) {
+                            if (b.fa && b.fb) { // split (python/RayTracer2.py:531-540): the reflected child as well
+                                RayState c = child_of(q, b, true, true);
+                                c.parent = myslot;
+                                const uint32_t at = wave_alloc_lds(&s_cnt[2]);
+                                if ((int64_t)at < a.seg_cap) store_ray(a.out, seg0 + (int64_t)at, c); else *a.overflow = 2;
+                            }
+                        }
                         RayState c = child_of(q, b, !b.fa, b.fa != 0);
                         c.parent = myslot;
-                        store_ray(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c);
+                        const uint32_t at = wave_alloc_lds(&s_cnt[2]);
+                        if (BF != 0 || (int64_t)at < a.seg_cap) store_ray(a.out, seg0 + (int64_t)at, c); else *a.overflow = 2;
                     }
                 }
             }
@@ -560,8 +571,9 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     if (threadIdx.x == 0) {
         if (s_cnt[0]) atomicAdd(&a.n_live[k], (unsigned long long)s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&a.n_scat[k], (unsigned long long)s_cnt[1]);
-        a.seg_out[blockIdx.x] = s_cnt[2];
-        if (s_cnt[2] > child0) atomicAdd(a.tail, (unsigned long long)(s_cnt[2] - child0));
+        const uint32_t kept = (int64_t)s_cnt[2] < a.seg_cap ? s_cnt[2] : (uint32_t)a.seg_cap; // beyond that: overflow, the run is repeated
+        a.seg_out[blockIdx.x] = kept;
+        if (kept > child0) atomicAdd(a.tail, (unsigned long long)(kept - child0));
         if constexpr (PASS == 1) a.defer_n[blockIdx.x] = s_cnt[3];
     }
 }
@@ -816,7 +828,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     ctx->K = K; ctx->n_rays = n; ctx->kernel_ms = 0; ctx->n_launches = 0;
     for (int i = 0; i < 3; i++) { ctx->ms_kind[i] = 0; ctx->n_kind[i] = 0; }
     // level-synchronous path: single-child runs with at most one child per ray and step
-    const bool level = single && ctx->level_steps > 0 && !(prm->follow_threshold[1] < 0);
+    const bool level = ctx->level_steps > 0 && (!single || !(prm->follow_threshold[1] < 0));
     if (level && ctx->lvl_K < K) { hipFree(ctx->d_lvl); ctx->d_lvl = nullptr; CK(hipMalloc(&ctx->d_lvl, sizeof(unsigned long long) * ((size_t)K + 2))); ctx->lvl_K = K; }
     ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
     ctx->fin.clear(); if (wantfin) ctx->fin.resize((size_t)n * FIN);
@@ -853,7 +865,12 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         }
     } else {
         chunk = std::min<int64_t>(n, ctx->nodice_chunk);
-        q_cap = std::max<int64_t>(4 * chunk, 1 << 16);
+        // every interaction above the thresholds spawns a reflected child: a generation can spawn many times the rays it
+        // was given (13 live rays per initial ray at the peak of the jar geometry, K = 18).  Room for 32 per ray of the
+        // pass if the workspace has it; an overflow is reported (-3) and the caller retries with smaller passes.
+        const size_t per_q = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4);
+        q_cap = std::max<int64_t>(std::min<int64_t>(32 * chunk, (int64_t)(W / per_q)), std::max<int64_t>(4 * chunk, 1 << 16));
+        q_cap += (int64_t)ctx->n_cu * 8; // segments of the level path round the capacity up
         if (full) rec_cap = std::max<int64_t>((int64_t)(W / rec_bytes), 1 << 16), rec_cap = std::min<int64_t>(rec_cap, (int64_t)1 << 31);
     }
     if (full && rec_cap < chunk) { rec_cap = chunk; }
@@ -861,7 +878,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     DevBuf b_hl, b_hso, b_seg, b_defer;
     const int nseg_max = ctx->n_cu * 8;
     // tally-only runs through a geometry with UNIFIED surfaces: those interactions get a launch of their own (k_level_phys PASS 1 + 2)
-    const bool defer = level && !out && ctx->has_unified && ctx->defer_unified;
+    const bool defer = level && single && !out && ctx->has_unified && ctx->defer_unified;
     if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 3 * (size_t)nseg_max)); }
     if (defer) CK(dev_alloc(ctx, b_defer, 2 * 4 * (size_t)q_cap));
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
@@ -889,7 +906,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
     a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base;
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
-    void (*kphys)(const KArgs) = out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : ((defer || !ctx->has_unified) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
+    void (*kphys)(const KArgs) = !single ? k_level_phys<FLAG_FULL | FLAG_FINAL> : out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : ((defer || !ctx->has_unified) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
     void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
     a.defer = (uint32_t*)b_defer.p; a.dense = defer ? (uint32_t*)b_defer.p + (size_t)q_cap : nullptr; a.defer_n = level ? (uint32_t*)b_seg.p + 2 * (size_t)nseg_max : nullptr;
     void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
@@ -926,7 +943,9 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (level) {
             // segments: nseg blocks, each owns seg_cap consecutive queue slots through all level steps
             const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * 8, (m + 4095) / 4096));
-            const int64_t seg_cap = (m + nseg - 1) / nseg;
+            const int64_t seg_fill = (m + nseg - 1) / nseg;
+            const int64_t seg_cap = single ? seg_fill : std::max<int64_t>(seg_fill, (q_cap - nseg) / nseg); // rays that split: room to grow
+            a.seg_fill = seg_fill;
             uint32_t* seg[2] = { (uint32_t*)b_seg.p, (uint32_t*)b_seg.p + nseg_max };
             CK(hipMemsetAsync(ctx->d_lvl, 0, sizeof(unsigned long long) * ((size_t)K + 2), ctx->stream));
             CK(hipMemsetAsync(b_seg.p, 0, sizeof(uint32_t) * 2 * (size_t)nseg_max, ctx->stream));
@@ -960,7 +979,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 CK(hipEventElapsedTime(&ms, ev1, ev2)); ctx->ms_kind[2] += ms; ctx->n_kind[2]++; ctx->kernel_ms += ms;
                 ctx->n_launches += defer ? 3 : 2;
                 int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
-                if (ovf) { ctx->err = "rt_trace: record buffer overflow (raise workspace)"; rc = -3; break; }
+                if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace or lower nodice_chunk)" : "rt_trace: ray queue overflow (lower nodice_chunk)"; rc = -3; break; }
                 live = (int64_t)nxt;
                 a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap;
                 cur ^= 1; sin ^= 1;

@@ -140,3 +140,23 @@ def test_unified_rays_get_their_own_launch(params, n_in, n_med):
     assert tabs[0].shape == ref.absorption_table.shape
     assert np.allclose(tabs[0], ref.absorption_table, rtol=1e-10, atol=1e-9)
     assert np.allclose(tabs[1], ref.absorption_table, rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("opts", [dict(level_steps=1000, level_min_rays=0), dict(level_steps=3, level_min_rays=0)])
+def test_ray_splitting_runs_on_the_level_path(opts):
+    """no-dice mode step by step: both children of every interaction go into the next step's queue (segments with room to
+    grow); records, table and final rows equal the oracle's, also when the persistent kernel takes over after 3 steps"""
+    sp, rays = cases.isotropic_rays(3000, 5, origin=(3, 0, 0), polarized=True)
+    args = ([10], [1e-9], np.array([1e-6, 1e-6]), [], True, False, False)
+    got = gpu_with(opts, sp, rays.copy(), cases.sphere_plane(), *args, compat="python-strict", return_final=True)
+    ref = O.trace(sp, rays.copy(), cases.sphere_plane(), *args, compat="python-strict", final=True)
+    compare_results(ref, got)
+    assert np.allclose(ref.final, got.final, rtol=1e-9, atol=1e-9, equal_nan=True)
+    sp, rays = cases.isotropic_rays(4000, 21, origin=(1, 2, 3), polarized=True)
+    args = (8, 1e-7, np.array([2e-2, 2e-2]), 0.5, True, False, False)
+    got = gpu_with(opts, sp, rays.copy(), cases.mixed_geometry(), *args, seed=32, compat="matlab")
+    ref = O.trace(sp, rays.copy(), cases.mixed_geometry(), *args, seed=32, compat="matlab")
+    compare_results(ref, got, growth=3.0)
+    # tallies only
+    got = gpu_with(opts, sp, rays.copy(), cases.mixed_geometry(), 8, 1e-7, np.array([2e-2, 2e-2]), 0.5, False, False, False, seed=32, compat="matlab")
+    assert np.allclose(ref.absorption_table, got.absorption_table, rtol=1e-7, atol=1e-7)
