@@ -45,6 +45,10 @@ def build_workload(name):
         sl = G.create_arbc_geometry(G.ArBCSpecs())
         origin = None
         kw = dict(K=18, min_travel=1e-5, thr=(1e-5, 100.0), tir=-1.0)
+    elif name == "arbc_nodice":  # ray splitting (no dice), the ray count grows ~13x before the thresholds bite
+        sl = G.create_arbc_geometry(G.ArBCSpecs())
+        origin = (0.0, 0.0, -5.0)
+        kw = dict(K=18, min_travel=1e-5, thr=(1e-5, 1e-5), tir=-1.0, flags=0)
     elif name == "sbc_lightcollection":
         sl = G.create_sbc_geometry()
         origin = (0.0, 0.6, 1.3)
@@ -115,7 +119,7 @@ def main():
     ctx = Context(local)
     ctx.set_program(*prog)
     S = prog[0].shape[0]
-    flags = _lib.FLAG_SINGLECHILD
+    flags = kw.get("flags", _lib.FLAG_SINGLECHILD)
     cam = None
     if origin is None:  # one ray per pixel of a 3:4 sensor with about --rays pixels
         from raytracer_amd import geometries as Gm
@@ -205,7 +209,7 @@ def main():
             "metric": "ray-surface interactions/sec (node) on SBC geometry", "value": inter_all / dt, "unit": "interactions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d-surface jar geometry, %s, MC single-child, K=%d, thr=%g, %d rays/step/GPU, full_output off"
+            "config": {"workload": ("%s: %d-surface jar geometry, %s, " + ("MC single-child" if flags & _lib.FLAG_SINGLECHILD else "ray splitting (no dice)") + ", K=%d, thr=%g, %d rays/step/GPU, full_output off")
                                    % (a.workload, S, ("point source" if h_sp is None else "point-source rays handed over as HOST arrays (PCIe-inclusive)") if cam is None
                                       else "camera rays generated on the device", kw["K"], kw["thr"][0], a.rays),
                        "rays_per_step_per_gpu": a.rays, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),

@@ -906,7 +906,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
     a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base;
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
-    void (*kphys)(const KArgs) = !single ? k_level_phys<FLAG_FULL | FLAG_FINAL> : out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : ((defer || !ctx->has_unified) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
+    void (*kphys)(const KArgs) = !single ? (out ? k_level_phys<FLAG_FULL | FLAG_FINAL> : k_level_phys<0>) : out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : ((defer || !ctx->has_unified) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
     void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
     a.defer = (uint32_t*)b_defer.p; a.dense = defer ? (uint32_t*)b_defer.p + (size_t)q_cap : nullptr; a.defer_n = level ? (uint32_t*)b_seg.p + 2 * (size_t)nseg_max : nullptr;
     void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
