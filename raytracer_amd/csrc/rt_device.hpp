@@ -1203,7 +1203,7 @@ RT_HD void rng_align(Rng& g, uint32_t idx) { g.idx = (idx + 1u) & ~1u; } // cont
 // The rejection loop of the facet normal (UnifiedReflectorModel.m:278-306) accepts about one draw in five at small
 // sigma_alpha, and a wave waits for its unluckiest ray.  The generator is counter-based, so try number j of a ray can
 // be evaluated before tries 0..j-1 are known to fail: the rays still drawing are spread over the 64 lanes, 64 / (rays
-// left) tries each, and every ray keeps the first of its tries that passes - the same normal, the same number of
+// left) tries each (rounded down), and every ray keeps the first of its tries that passes - the same normal, the same number of
 // uniforms consumed as the ray-by-ray loop (the oracle's).  All 64 lanes must call (EXEC full); `need` marks the rays.
 __device__ __forceinline__ double rng_uniform_at(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t step, uint32_t k0, uint32_t k1, uint32_t i) {
     uint32_t o0, o1, o2, o3;
@@ -1230,7 +1230,7 @@ __device__ __forceinline__ V3 facet_normal_wave(bool need, Rng& g, V3 indir, V3 
     const uint32_t idx0 = g.idx;
     while (pending) {
         const int np = __popcll(pending);
-        int c = 1; while (2 * c * np <= 64) c *= 2;                    // tries per ray this round
+        const int c = 64 / np;                                          // tries per ray this round
         const int rank = __popcll(pending & ((1ull << lane) - 1ull));  // my ray's place among the rays still drawing
         const bool mine = (pending >> lane) & 1ull;
         // rank -> lane: every drawing lane sends its number to the lane of its rank
