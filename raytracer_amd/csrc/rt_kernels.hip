@@ -637,7 +637,7 @@ struct rt_ctx {
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 16;
+    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, seg_per_cu = 8;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
 };
 
@@ -666,6 +666,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     const char* ls = getenv("RT_LEVEL_STEPS"); if (ls && atoi(ls) >= 0) ctx->level_steps = atoi(ls);
     const char* lm = getenv("RT_LEVEL_MIN_RAYS"); if (lm && atoll(lm) >= 0) ctx->level_min_rays = atoll(lm);
     const char* hs = getenv("RT_HIT_SPLIT"); if (hs && atoi(hs) > 0) ctx->hit_split = atoi(hs);
+    const char* sc = getenv("RT_SEG_PER_CU"); if (sc && atoi(sc) > 0 && atoi(sc) <= 64) ctx->seg_per_cu = atoi(sc);
     const char* hb = getenv("RT_HIT_BLOCKS_PER_CU"); if (hb && atoi(hb) >= 0) ctx->hit_blocks_per_cu = atoi(hb);
     const char* pb = getenv("RT_PHYS_BLOCKS_PER_CU"); if (pb && atoi(pb) >= 0) ctx->phys_blocks_per_cu = atoi(pb);
     *out = ctx; return 0;
@@ -861,7 +862,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (level) { // two ray queues (ping-pong) + the hit of every live ray
             const size_t per_ray = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12 + 8; // + hit (12 B) + the two ray lists of the physics launches (4 B each)
             chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / per_ray)));
-            q_cap = chunk + (int64_t)ctx->n_cu * 8; // segments round the capacity up
+            q_cap = chunk + (int64_t)ctx->n_cu * ctx->seg_per_cu; // segments round the capacity up
         }
     } else {
         chunk = std::min<int64_t>(n, ctx->nodice_chunk);
@@ -870,13 +871,13 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         // pass if the workspace has it; an overflow is reported (-3) and the caller retries with smaller passes.
         const size_t per_q = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4);
         q_cap = std::max<int64_t>(std::min<int64_t>(32 * chunk, (int64_t)(W / per_q)), std::max<int64_t>(4 * chunk, 1 << 16));
-        q_cap += (int64_t)ctx->n_cu * 8; // segments of the level path round the capacity up
+        q_cap += (int64_t)ctx->n_cu * ctx->seg_per_cu; // segments of the level path round the capacity up
         if (full) rec_cap = std::max<int64_t>((int64_t)(W / rec_bytes), 1 << 16), rec_cap = std::min<int64_t>(rec_cap, (int64_t)1 << 31);
     }
     if (full && rec_cap < chunk) { rec_cap = chunk; }
 
     DevBuf b_hl, b_hso, b_seg, b_defer;
-    const int nseg_max = ctx->n_cu * 8;
+    const int nseg_max = ctx->n_cu * ctx->seg_per_cu;
     // tally-only runs through a geometry with UNIFIED surfaces: those interactions get a launch of their own (k_level_phys PASS 1 + 2)
     const bool defer = level && single && !out && ctx->has_unified && ctx->defer_unified;
     if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 3 * (size_t)nseg_max)); }
@@ -942,7 +943,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         int64_t live = m; int k0 = 0;
         if (level) {
             // segments: nseg blocks, each owns seg_cap consecutive queue slots through all level steps
-            const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * 8, (m + 4095) / 4096));
+            const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * ctx->seg_per_cu, (m + 4095) / 4096));
             const int64_t seg_fill = (m + nseg - 1) / nseg;
             const int64_t seg_cap = single ? seg_fill : std::max<int64_t>(seg_fill, (q_cap - nseg) / nseg); // rays that split: room to grow
             a.seg_fill = seg_fill;
