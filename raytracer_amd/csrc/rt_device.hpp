@@ -1430,7 +1430,9 @@ RT_HD void bounce_hit(const Geom& G, const Prm& P, RayState& q, bool act, Hit& h
 }
 // CF >= 0: the flags are known at compile time (the kernel is instantiated per flag set, so that fields of Bounce that
 // only feed records/final rows are dead code in the tally-only variants); CF < 0: read P.flags.
-template <int CF = -1> RT_HD void bounce_phys(const Geom& G, const Prm& P, RayState& q, const Hit& h, Bounce& b) {
+// NOUNI: the geometry has no UNIFIED surface (the caller checked); the rough-surface model and the registers its call
+// costs are then not compiled in.
+template <int CF = -1, bool NOUNI = false> RT_HD void bounce_phys(const Geom& G, const Prm& P, RayState& q, const Hit& h, Bounce& b) {
     const int flags = CF >= 0 ? CF : P.flags;
     Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
@@ -1462,7 +1464,7 @@ template <int CF = -1> RT_HD void bounce_phys(const Geom& G, const Prm& P, RaySt
     double l_bulk = INFINITY;
     if (b.rayl1 < INFINITY) l_bulk = -b.rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
     b.surf_sc = h.l <= l_bulk; b.ray_sc = !b.surf_sc;
-    bool uni_sc = b.surf_sc && st == ST_UNIFIED, nor_sc = b.surf_sc && !uni_sc;
+    bool uni_sc = !NOUNI && b.surf_sc && st == ST_UNIFIED, nor_sc = b.surf_sc && !uni_sc;
     if (b.ray_sc) { b.six_next = 0; b.l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
     b.p = pn;
     double trans = exp(-b.l / b.absl1); // :424-427
@@ -1470,10 +1472,12 @@ template <int CF = -1> RT_HD void bounce_phys(const Geom& G, const Prm& P, RaySt
     b.inc = q.r; b.inc.s0 *= trans; b.inc.s1 *= trans; b.inc.s2 *= trans; b.inc.s3 *= trans;
     b.refr = b.inc; b.refr.s0 = b.refr.s1 = b.refr.s2 = b.refr.s3 = 0; b.refl = b.refr;
     if (nor_sc) fresnel(b.inc, sopt, b.n1, b.n2, P.tir, b.refr, b.refl); // :438-439
-    if (uni_sc) { // :443-444
-        double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
-        UnifiedOut u = unified(g, b.inc, b.nmech, b.n1, b.n2, row[22], row[23], c1, c2, c3, P.maxiter);
-        b.refl = u.r; rng_align(g, u.idx);
+    if constexpr (!NOUNI) {
+        if (uni_sc) { // :443-444
+            double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
+            UnifiedOut u = unified(g, b.inc, b.nmech, b.n1, b.n2, row[22], row[23], c1, c2, c3, P.maxiter);
+            b.refl = u.r; rng_align(g, u.idx);
+        }
     }
     if (b.surf_sc) { double f = 1 - absn; b.refr.s0 *= f; b.refr.s1 *= f; b.refr.s2 *= f; b.refr.s3 *= f; b.refl.s0 *= f; b.refl.s1 *= f; b.refl.s2 *= f; b.refl.s3 *= f; } // :447-449
     if (b.ray_sc) b.refl = rayleigh(g, b.inc, G.lut, G.lut_prec); // :452-454

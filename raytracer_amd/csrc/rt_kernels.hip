@@ -462,6 +462,7 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
 
 // PASS 0: every ray of the segment.  PASS 1: rays ending on a UNIFIED surface are only listed (KArgs::defer).
 // PASS 2: the listed rays, children appended behind those of pass 1.  Passes 1 and 2 exist for CF == FLAG_SINGLE.
+// PASS 3: PASS 0 for a geometry without UNIFIED surfaces (no such code in the kernel).
 template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS == 2 ? RT_UNI_WAVES : RT_PHYS_WAVES) k_level_phys(const KArgs a) {
     extern __shared__ double smem[];
     if constexpr (PASS == 2) { if (a.defer_n[blockIdx.x] == 0) return; } // nothing put aside in this segment
@@ -529,7 +530,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
                 }
             } else {
                 Bounce b; b.scat = 0;
-                bounce_phys<BF>(G, P, q, h, b);
+                bounce_phys<BF, PASS == 3>(G, P, q, h, b);
                 if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
                 else {
                     atomicAdd(&s_cnt[1], 1u);
@@ -907,7 +908,10 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
     a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base;
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
-    void (*kphys)(const KArgs) = !single ? (out ? k_level_phys<FLAG_FULL | FLAG_FINAL> : k_level_phys<0>) : out ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : ((defer || !ctx->has_unified) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
+    const bool nu = !ctx->has_unified;
+    void (*kphys)(const KArgs) = !single ? (out ? (nu ? k_level_phys<FLAG_FULL | FLAG_FINAL, 3> : k_level_phys<FLAG_FULL | FLAG_FINAL>) : (nu ? k_level_phys<0, 3> : k_level_phys<0>)) :
+                                 out ? (nu ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL, 3> : k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL>) :
+                                 ((defer || nu) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
     void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
     a.defer = (uint32_t*)b_defer.p; a.dense = defer ? (uint32_t*)b_defer.p + (size_t)q_cap : nullptr; a.defer_n = level ? (uint32_t*)b_seg.p + 2 * (size_t)nseg_max : nullptr;
     void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
