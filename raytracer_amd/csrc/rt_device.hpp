@@ -1430,9 +1430,9 @@ RT_HD void bounce_hit(const Geom& G, const Prm& P, RayState& q, bool act, Hit& h
 }
 // CF >= 0: the flags are known at compile time (the kernel is instantiated per flag set, so that fields of Bounce that
 // only feed records/final rows are dead code in the tally-only variants); CF < 0: read P.flags.
-// NOUNI: the geometry has no UNIFIED surface (the caller checked); the rough-surface model and the registers its call
-// costs are then not compiled in.
-template <int CF = -1, bool NOUNI = false> RT_HD void bounce_phys(const Geom& G, const Prm& P, RayState& q, const Hit& h, Bounce& b) {
+// UNI = 2: no ray that comes here ends on a UNIFIED surface (the caller checked); the rough-surface model and the
+// registers its call costs are then not compiled in.  UNI = 1: the model in line (a launch of UNIFIED rays only).
+template <int CF = -1, int UNI = 0> RT_HD void bounce_phys(const Geom& G, const Prm& P, RayState& q, const Hit& h, Bounce& b) {
     const int flags = CF >= 0 ? CF : P.flags;
     Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
@@ -1464,7 +1464,7 @@ template <int CF = -1, bool NOUNI = false> RT_HD void bounce_phys(const Geom& G,
     double l_bulk = INFINITY;
     if (b.rayl1 < INFINITY) l_bulk = -b.rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
     b.surf_sc = h.l <= l_bulk; b.ray_sc = !b.surf_sc;
-    bool uni_sc = !NOUNI && b.surf_sc && st == ST_UNIFIED, nor_sc = b.surf_sc && !uni_sc;
+    bool uni_sc = UNI != 2 && b.surf_sc && st == ST_UNIFIED, nor_sc = b.surf_sc && !uni_sc;
     if (b.ray_sc) { b.six_next = 0; b.l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
     b.p = pn;
     double trans = exp(-b.l / b.absl1); // :424-427
@@ -1472,10 +1472,12 @@ template <int CF = -1, bool NOUNI = false> RT_HD void bounce_phys(const Geom& G,
     b.inc = q.r; b.inc.s0 *= trans; b.inc.s1 *= trans; b.inc.s2 *= trans; b.inc.s3 *= trans;
     b.refr = b.inc; b.refr.s0 = b.refr.s1 = b.refr.s2 = b.refr.s3 = 0; b.refl = b.refr;
     if (nor_sc) fresnel(b.inc, sopt, b.n1, b.n2, P.tir, b.refr, b.refl); // :438-439
-    if constexpr (!NOUNI) {
+    if constexpr (UNI != 2) {
         if (uni_sc) { // :443-444
             double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
-            UnifiedOut u = unified(g, b.inc, b.nmech, b.n1, b.n2, row[22], row[23], c1, c2, c3, P.maxiter);
+            UnifiedOut u;
+            if constexpr (UNI == 1) u = unified_body(g, b.inc, b.nmech, b.n1, b.n2, row[22], row[23], c1, c2, c3, P.maxiter);
+            else u = unified(g, b.inc, b.nmech, b.n1, b.n2, row[22], row[23], c1, c2, c3, P.maxiter);
             b.refl = u.r; rng_align(g, u.idx);
         }
     }

@@ -461,7 +461,8 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
 }
 
 // PASS 0: every ray of the segment.  PASS 1: rays ending on a UNIFIED surface are only listed (KArgs::defer).
-// PASS 2: the listed rays, children appended behind those of pass 1.  Passes 1 and 2 exist for CF == FLAG_SINGLE.
+// PASS 2: the listed rays, children appended behind those of pass 1; for CF == FLAG_SINGLE (tallies only) the wave
+// works through the UNIFIED model together (unified_wave), otherwise every lane runs it in line.
 // PASS 3: PASS 0 for a geometry without UNIFIED surfaces (no such code in the kernel).
 template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS == 2 ? RT_UNI_WAVES : RT_PHYS_WAVES) k_level_phys(const KArgs a) {
     extern __shared__ double smem[];
@@ -503,8 +504,9 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
         // PASS 2: the wave works together on the rough-surface loop (unified_wave), so all 64 lanes go through the step;
         // those behind the end of the list repeat its last ray and leave no trace
         const bool act = idx < n;
-        if constexpr (PASS == 2) { if (!act) idx = n - 1; }
-        if (act || PASS == 2) {
+        constexpr bool WAVE = PASS == 2 && CF == FLAG_SINGLE;
+        if constexpr (WAVE) { if (!act) idx = n - 1; }
+        if (act || WAVE) {
             if (listed) idx = seg0 + (int64_t)list[idx];
             const int so = a.hit_so[idx];
             RayState q; load_queue_ray(a, idx, q);
@@ -530,7 +532,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
                 }
             } else {
                 Bounce b; b.scat = 0;
-                bounce_phys<BF, PASS == 3>(G, P, q, h, b);
+                bounce_phys<BF, PASS == 2 ? 1 : ((PASS == 1 || PASS == 3) ? 2 : 0)>(G, P, q, h, b);
                 if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
                 else {
                     atomicAdd(&s_cnt[1], 1u);
@@ -867,11 +869,12 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         }
     } else {
         chunk = std::min<int64_t>(n, ctx->nodice_chunk);
-        // every interaction above the thresholds spawns a reflected child: a generation can spawn many times the rays it
-        // was given (13 live rays per initial ray at the peak of the jar geometry, K = 18).  Room for 32 per ray of the
-        // pass if the workspace has it; an overflow is reported (-3) and the caller retries with smaller passes.
-        const size_t per_q = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4);
-        q_cap = std::max<int64_t>(std::min<int64_t>(32 * chunk, (int64_t)(W / per_q)), std::max<int64_t>(4 * chunk, 1 << 16));
+        // every interaction above the thresholds spawns a reflected child: the live count can grow by 2 per step (13 live
+        // rays per initial ray at the peak of the jar geometry with black reflectors, K = 18; far more with reflective
+        // ones).  The queues take the whole workspace (at most 1024 rays per ray of the pass), so that a smaller pass has
+        // more room per ray; an overflow is reported (-3) and the caller retries with smaller passes.
+        const size_t per_q = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12 + 8;
+        q_cap = std::max<int64_t>(std::min<int64_t>(1024 * chunk, (int64_t)(W / per_q)), std::max<int64_t>(4 * chunk, 1 << 16));
         q_cap += (int64_t)ctx->n_cu * ctx->seg_per_cu; // segments of the level path round the capacity up
         if (full) rec_cap = std::max<int64_t>((int64_t)(W / rec_bytes), 1 << 16), rec_cap = std::min<int64_t>(rec_cap, (int64_t)1 << 31);
     }
@@ -879,8 +882,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 
     DevBuf b_hl, b_hso, b_seg, b_defer;
     const int nseg_max = ctx->n_cu * ctx->seg_per_cu;
-    // tally-only runs through a geometry with UNIFIED surfaces: those interactions get a launch of their own (k_level_phys PASS 1 + 2)
-    const bool defer = level && single && !out && ctx->has_unified && ctx->defer_unified;
+    // geometry with UNIFIED surfaces: the rays that end on them get a physics launch of their own (k_level_phys PASS 1 + 2)
+    const bool defer = level && ctx->has_unified && ctx->defer_unified;
     if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 3 * (size_t)nseg_max)); }
     if (defer) CK(dev_alloc(ctx, b_defer, 2 * 4 * (size_t)q_cap));
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
@@ -908,11 +911,13 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
     a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base;
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
+    // k_level_phys variants: 3 = geometry without UNIFIED surfaces; 1 + 2 = those rays in a launch of their own; 0 = one launch
     const bool nu = !ctx->has_unified;
-    void (*kphys)(const KArgs) = !single ? (out ? (nu ? k_level_phys<FLAG_FULL | FLAG_FINAL, 3> : k_level_phys<FLAG_FULL | FLAG_FINAL>) : (nu ? k_level_phys<0, 3> : k_level_phys<0>)) :
-                                 out ? (nu ? k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL, 3> : k_level_phys<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL>) :
-                                 ((defer || nu) ? k_level_phys<FLAG_SINGLE, 1> : k_level_phys<FLAG_SINGLE>); // pass 1 carries no UNIFIED code
-    void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
+    void (*kphys)(const KArgs); void (*kphys2)(const KArgs) = nullptr;
+#define RT_PICK(CF_) { if (nu) kphys = k_level_phys<CF_, (CF_) == FLAG_SINGLE ? 1 : 3>; else if (defer) { kphys = k_level_phys<CF_, 1>; kphys2 = k_level_phys<CF_, 2>; } else kphys = k_level_phys<CF_, 0>; }
+    if (!single) { if (out) RT_PICK(FLAG_FULL | FLAG_FINAL) else RT_PICK(0) }
+    else { if (out) RT_PICK(FLAG_SINGLE | FLAG_FULL | FLAG_FINAL) else RT_PICK(FLAG_SINGLE) }
+#undef RT_PICK
     a.defer = (uint32_t*)b_defer.p; a.dense = defer ? (uint32_t*)b_defer.p + (size_t)q_cap : nullptr; a.defer_n = level ? (uint32_t*)b_seg.p + 2 * (size_t)nseg_max : nullptr;
     void (*kinit)(const KArgs) = out ? k_level_init<FLAG_FULL | FLAG_FINAL> : k_level_init<0>;
     const bool prog_generic = !(ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2)) || ctx->frames_have_generic;
@@ -947,7 +952,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         int64_t live = m; int k0 = 0;
         if (level) {
             // segments: nseg blocks, each owns seg_cap consecutive queue slots through all level steps
-            const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * ctx->seg_per_cu, (m + 4095) / 4096));
+            // one block of the physics kernel per segment: enough of them to fill the machine once the rays have multiplied
+            const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * ctx->seg_per_cu, ((single ? m : std::min<int64_t>(q_cap, 64 * m)) + 511) / 512));
             const int64_t seg_fill = (m + nseg - 1) / nseg;
             const int64_t seg_cap = single ? seg_fill : std::max<int64_t>(seg_fill, (q_cap - nseg) / nseg); // rays that split: room to grow
             a.seg_fill = seg_fill;
