@@ -223,6 +223,12 @@ int rt_result_num_records(rt_ctx* ctx, int64_t* n);
 int rt_result_records(rt_ctx* ctx, double* rec /*[n][RT_REC_COLS]*/, int32_t* step /*[n]*/,
                       int64_t* ray_id /*[n]*/, int64_t* parent /*[n]*/, int32_t* flags /*[n]*/);
 int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);
+/* Final rows without the trip through host memory (no reference counterpart; the reference's reduction,
+ * python/BubbleImageCreator.py:134-165, lives in host arrays): traces with RT_FLAG_FINAL_ROWS write row (ray id -
+ * ray_id_base) straight into d_rows, a device buffer of the caller's with room for n_rows rows (e.g. a torch tensor),
+ * and rt_result_final has nothing to return.  rt_match_endpoints takes such buffers as they are.  d_rows = NULL
+ * restores the host copy. */
+int rt_set_final_rows_device(rt_ctx* ctx, double* d_rows, int64_t n_rows);
 /* kernel time of the last trace (or rt_match_endpoints call) measured with HIP events on the context's stream, and launch count */
 int rt_result_timing(rt_ctx* ctx, double* kernel_ms, int32_t* n_launches);
 /* the same split by kernel: [0] k_trace (persistent bounce kernel), [1] k_level_hit, [2] k_level_phys */

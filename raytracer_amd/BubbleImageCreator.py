@@ -111,18 +111,22 @@ def arbc_lights(geospecs, rng=None):
 
 
 def create_bubble_image(surface_list, cam, led_startingpoints, led_rays, max_scat=18, min_travel_len=1e-5, follow_thresh=(1e-5, 100),
-                        descriptions=LIGHT_SURFACES, compat="python", seed=None, ctx=None, device=0, **match_kw):
+                        descriptions=LIGHT_SURFACES, compat="python", seed=None, ctx=None, device=0, on_device=False, **match_kw):
     """The whole of python/BubbleImageCreator.py:125-357 for one camera: returns a dict with `image` (pixel_intensity
-    shaped [resolution[0], resolution[1]], pixel (i, j) at [i-1, j-1]), the final rows of both traces and the tables."""
+    shaped [resolution[0], resolution[1]], pixel (i, j) at [i-1, j-1]), the final rows of both traces and the tables.
+    on_device=True keeps the final rows of both traces in HBM (torch tensors): only the pixel intensities cross PCIe."""
     c = ctx if ctx is not None else _rt.get_context(device)
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
-    tab_c, fin_c, _ = _rt.trace_camera(cam, surface_list, max_scat, min_travel_len, follow_thresh, compat=compat, seed=seed, ctx=c)       # :129
+    tab_c, fin_c, _ = _rt.trace_camera(cam, surface_list, max_scat, min_travel_len, follow_thresh, compat=compat, seed=seed, ctx=c,
+                                       device_rows=on_device)                                                                          # :129
     out = _rt.RayTracer2(led_startingpoints, led_rays, surface_list, max_scat, min_travel_len, follow_thresh, full_output=False,
-                         compat=compat, seed=seed + 1, ctx=c, return_final=True)                                                        # :185
+                         compat=compat, seed=seed + 1, ctx=c, return_final="device" if on_device else True)                             # :185
     fin_l = out[3]
     sf = light_surface_indices(surface_list, descriptions, compat)
     pix = match_leds_to_camera(fin_c, fin_l, sf, ctx=c, **match_kw)
+    if on_device:
+        pix = pix.cpu().numpy()
     res = (int(cam.resolution[0]), int(cam.resolution[1]))
     return {"image": pix.reshape(res, order="F"), "pixel_intensity": pix, "final_cam": fin_c, "final_led": fin_l,
             "table_cam": tab_c, "table_led": out[1], "light_surfaces": sf}

@@ -17,7 +17,8 @@ Differences a caller can see, all deliberate (SURVEY.md quirk ledger):
   * randomness is a counter-based Philox stream keyed by (seed, ray id, path, step): results do not depend on the
     number of GPUs or on chunking.  `seed=None` draws the seed from numpy's global stream, so `np.random.seed()`
     still makes runs repeatable.
-Keyword-only extras: compat, seed, device, return_final, ray_id_base, ctx.
+Keyword-only extras: compat, seed, device, return_final (True: rows as a numpy array; "device": as a torch tensor in
+HBM), ray_id_base, ctx.
 """
 import ctypes as C
 
@@ -111,6 +112,18 @@ class Context(object):
         out["kernel_ms"] = ms.value; out["n_launches"] = nl.value
         return out
 
+    def final_rows_device(self, n_rays):
+        """a torch tensor [n_rays][32] on this context's GPU that the next traces with final rows write into (see
+        rt_set_final_rows_device); release with final_rows_host()"""
+        import torch
+        t = torch.zeros((int(n_rays), _lib.FINAL_COLS), dtype=torch.float64, device="cuda:%d" % int(self.device))
+        torch.cuda.synchronize(t.device)
+        self._check(self.L.rt_set_final_rows_device(self.h, C.c_void_p(t.data_ptr()), int(n_rays)))
+        return t
+
+    def final_rows_host(self):
+        self._check(self.L.rt_set_final_rows_device(self.h, None, 0))
+
     def step_counts(self, K):
         live = np.zeros(K, np.int64); scat = np.zeros(K, np.int64)
         self._check(self.L.rt_result_step_counts(self.h, live.ctypes.data_as(C.POINTER(C.c_int64)), scat.ctypes.data_as(C.POINTER(C.c_int64))))
@@ -132,7 +145,7 @@ def _surface_fingerprint(s):
 
 def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.float64(1)), follow_thresh=np.array([0, 0], dtype=np.float64),
                  tir_handling=[], full_output=False, singlechild=True, *, compat="python", seed=None, device=0, ctx=None, ray_id_base=0,
-                 unified_maxiter=0):
+                 unified_maxiter=0, device_rows=False):
     """The camera run of python/BubbleImageCreator.py:129 without host arrays: rays are generated in HBM from the
     rt_camera `cam` (GenerateRaysFromCamera.make_camera), traced, and reduced to the final row per pixel
     (BubbleImageCreator.py:149-161).  Returns (absorption_table, final_rows[n_pixels][32], ray_interfaces or [])."""
@@ -153,8 +166,15 @@ def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.flo
     c.set_surfaces(surfacelist, nobulk=(compat == "python-strict"))
     flags = (_lib.FLAG_FULL_OUTPUT if full_output else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | _lib.FLAG_FINAL_ROWS
     prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
-    c._check(c.L.rt_trace_camera(c.h, C.byref(cam), C.byref(prm)))
-    res = c.results(bool(full_output), True, n)
+    rows = c.final_rows_device(n) if device_rows else None
+    try:
+        c._check(c.L.rt_trace_camera(c.h, C.byref(cam), C.byref(prm)))
+    finally:
+        if device_rows:
+            c.final_rows_host()
+    res = c.results(bool(full_output), not device_rows, n)
+    if device_rows:
+        res["final"] = rows
     ris = []
     if full_output:
         groups = order_records(res["step"], res["ray"], res["parent"], res["flags"], res["num_steps"])
@@ -293,6 +313,7 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
     chunk = None
     sink = None
+    dev_rows = c.final_rows_device(n) if (isinstance(return_final, str) and return_final == "device") else None
     if record_sink is not None:  # streaming: records leave chunk by chunk; ray_interfaces comes back empty
         if not full_output or output_raytable or not singlechild:
             raise ValueError("record_sink needs full_output=True, singlechild=True and output_raytable=False")
@@ -313,7 +334,11 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     finally:
         if sink is not None:
             c.L.rt_set_record_sink(c.h, C.cast(None, _lib.RECORD_SINK), None)
-    res = c.results(want_rec, return_final, n)
+        if dev_rows is not None:
+            c.final_rows_host()
+    res = c.results(want_rec, bool(return_final) and dev_rows is None, n)
+    if dev_rows is not None:
+        res["final"] = dev_rows
     ns = res["num_steps"]
     base = 0 if (COMPAT[compat] & _lib.COMPAT_PY_INDEX) else 1
 

@@ -11,7 +11,7 @@ FLAG_FULL_OUTPUT, FLAG_SINGLECHILD, FLAG_FINAL_ROWS = 1, 2, 4
 COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
 
 EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device",
-           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_record_sink", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_table",
+           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_record_sink", "rt_set_final_rows_device", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_table",
            "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_final", "rt_result_timing",
            "rt_result_timing_by_kernel", "rt_device_info")
 
@@ -51,6 +51,12 @@ def load():
     if not os.path.exists(SO_PATH):
         raise RayTracerLibraryError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(hipcc --offload-arch=gfx950).  raytracer_amd has no CPU path." % SO_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64, and when this library has already pulled in the
+    # system's, torch later finds "No HIP GPUs".  Loading torch first (if it is installed) makes both use torch's.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(SO_PATH)
     P = C.POINTER
     L.rt_init.argtypes = [C.c_int, P(C.c_void_p)]
@@ -67,6 +73,7 @@ def load():
     L.rt_set_record_sink.argtypes = [C.c_void_p, RECORD_SINK, C.c_void_p]
     L.rt_match_endpoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, P(C.c_int32), C.c_int32, P(MatchParams),
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_set_final_rows_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.rt_result_num_steps.argtypes = [C.c_void_p, P(C.c_int32)]
     L.rt_result_table.argtypes = [C.c_void_p, P(C.c_double)]

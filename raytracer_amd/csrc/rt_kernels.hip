@@ -633,6 +633,7 @@ struct rt_ctx {
     std::vector<double> table; std::vector<int64_t> n_live, n_scat;
     std::vector<double> rec; std::vector<int32_t> rec_step, rec_flags; std::vector<int64_t> rec_ray, rec_parent;
     std::vector<double> fin;
+    double* d_fin_user = nullptr; int64_t fin_user_rows = 0; // rt_set_final_rows_device: final rows stay in the caller's device buffer
     std::vector<std::pair<void*, size_t>> pool; // cached device buffers (see DevBuf)
     rt_record_sink sink = nullptr; void* sink_user = nullptr; // records leave chunk by chunk instead of accumulating
     double kernel_ms = 0; int n_launches = 0;
@@ -770,6 +771,10 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
     return 0;
 }
 
+extern "C" int rt_set_final_rows_device(rt_ctx* ctx, double* d_rows, int64_t n_rows) {
+    if (d_rows && n_rows <= 0) { ctx->err = "rt_set_final_rows_device: no rows"; return -1; }
+    ctx->d_fin_user = d_rows; ctx->fin_user_rows = d_rows ? n_rows : 0; return 0;
+}
 extern "C" int rt_set_record_sink(rt_ctx* ctx, rt_record_sink sink, void* user) { ctx->sink = sink; ctx->sink_user = user; return 0; }
 
 extern "C" int rt_set_rayleigh_lut(rt_ctx* ctx, const double* lut, int32_t n) {
@@ -835,7 +840,9 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     const bool level = ctx->level_steps > 0 && (!single || !(prm->follow_threshold[1] < 0));
     if (level && ctx->lvl_K < K) { hipFree(ctx->d_lvl); ctx->d_lvl = nullptr; CK(hipMalloc(&ctx->d_lvl, sizeof(unsigned long long) * ((size_t)K + 2))); ctx->lvl_K = K; }
     ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
-    ctx->fin.clear(); if (wantfin) ctx->fin.resize((size_t)n * FIN);
+    const bool fin_dev = wantfin && ctx->d_fin_user != nullptr;
+    if (fin_dev && n > ctx->fin_user_rows) { ctx->err = "rt_trace: the device buffer for the final rows is smaller than the number of rays"; return -1; }
+    ctx->fin.clear(); if (wantfin && !fin_dev) ctx->fin.resize((size_t)n * FIN);
 
     // ---- LDS budget: surface rows + as many absorption_table rows as fit in lds_budget (the first steps carry almost
     // all interactions; deeper rows go to global atomics)
@@ -894,7 +901,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         CK(dev_alloc(ctx, b_rec, (size_t)REC * 8 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rstep, 4 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rray, 8 * (size_t)rec_cap));
         CK(dev_alloc(ctx, b_rpar, 8 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rflag, 4 * (size_t)rec_cap));
     }
-    if (wantfin) CK(dev_alloc(ctx, b_fin, (size_t)FIN * 8 * (size_t)chunk));
+    if (wantfin && !fin_dev) CK(dev_alloc(ctx, b_fin, (size_t)FIN * 8 * (size_t)chunk));
 
     KArgs a; memset(&a, 0, sizeof a);
     a.surf = ctx->d_surf; a.S = S; a.recs = ctx->d_recs; a.smeta = ctx->d_smeta;
@@ -939,6 +946,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         int64_t m = std::min<int64_t>(chunk, n - off);
         CK(hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
         a.mode = mode; a.n_in = m; a.ray_id_base = prm->ray_id_base + off; a.slot_base = prm->ray_id_base + off;
+        if (fin_dev) a.fin = ctx->d_fin_user + (size_t)off * FIN;
         if (mode == 0) {
             if (d_soa) { a.in_d = d_soa + off; a.in_stride = n; }
             else {
@@ -1054,7 +1062,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 }
             }
         }
-        if (wantfin) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));
+        if (wantfin && !fin_dev) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));
     }
     hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(ev2); hipEventDestroy(ev3);
     if (rc) return rc;

@@ -139,7 +139,7 @@ def test_bubble_image_pipeline():
     sp, rays = arbc_lights(specs, np.random.default_rng(3))
     # with the dimensions of CreateArBCGeometry.m the camera mostly sees the top cone: let it give light too
     lit = LIGHT_SURFACES + ('reflector/diffuser topcone',)
-    out = create_bubble_image(sl, cam, sp, rays, seed=17, descriptions=lit)
+    out = create_bubble_image(sl, cam, sp, rays.copy(), seed=17, descriptions=lit)   # RayTracer2 normalises its `rays` argument in place
     assert out["image"].shape == (48, 64)
     fin_c, fin_l = out["final_cam"], out["final_led"]
     sf = light_surface_indices(sl, lit)
@@ -148,6 +148,11 @@ def test_bubble_image_pipeline():
     assert (lc0 >= 0).sum() > 50 and np.count_nonzero(pix0) > 20
     assert np.allclose(out["pixel_intensity"], pix0, rtol=1e-9, atol=1e-300)
     assert np.array_equal(out["image"][5, 7], out["pixel_intensity"][7 * 48 + 5])
+    # the same with the final rows of both traces left in HBM (rt_set_final_rows_device): identical end points and image
+    dev = create_bubble_image(sl, cam, sp, rays.copy(), seed=17, descriptions=lit, on_device=True)
+    assert np.array_equal(dev["final_cam"].cpu().numpy(), fin_c, equal_nan=True)
+    assert np.array_equal(dev["final_led"].cpu().numpy(), fin_l, equal_nan=True)
+    assert np.allclose(dev["pixel_intensity"], out["pixel_intensity"], rtol=1e-12, atol=1e-300)
     # LED end points: kernel reduction == reference reduction over the records of the same run
     ri, _, _, fin = RayTracer2(sp, rays.copy(), sl, 18, 1e-5, [1e-5, 100], seed=18, return_final=True)
     assert fin.shape == fin_l.shape
