@@ -57,3 +57,27 @@ def test_camera_run_on_the_jar_geometry():
             last[i] = np.asarray(r.intersection_point)[k]
     idx = np.array(sorted(last)); pts = np.array([last[i] for i in idx])
     assert np.allclose(final[idx - 1, 0:3], pts, rtol=1e-12, atol=1e-12)   # compat='matlab': ray_index is 1-based
+
+
+def test_final_rows_device_buffer_too_small():
+    """rt_set_final_rows_device: a buffer with fewer rows than rays is refused before anything runs, and the context is
+    usable afterwards"""
+    import torch
+    from raytracer_amd import geometries as G
+    from raytracer_amd._lib import RayTracerLibraryError
+    from raytracer_amd.RayTracer2 import Context, trace_camera
+    import ctypes as C
+    specs = G.ArBCSpecs(cam_resolution=np.array([40, 50]))
+    sl = G.create_arbc_geometry(specs); cam = G.arbc_camera(specs)
+    c = Context(0)
+    try:
+        small = torch.zeros((100, 32), dtype=torch.float64, device="cuda:0")
+        c._check(c.L.rt_set_final_rows_device(c.h, C.c_void_p(small.data_ptr()), 100))
+        with pytest.raises(RayTracerLibraryError):
+            trace_camera(cam, sl, 18, 1e-5, [1e-5, 100], ctx=c, seed=1)
+        c.final_rows_host()
+        _, host_rows, _ = trace_camera(cam, sl, 18, 1e-5, [1e-5, 100], ctx=c, seed=1)
+        _, dev_rows, _ = trace_camera(cam, sl, 18, 1e-5, [1e-5, 100], ctx=c, seed=1, device_rows=True)
+        assert np.array_equal(dev_rows.cpu().numpy(), host_rows, equal_nan=True)
+    finally:
+        c.close()
