@@ -37,6 +37,7 @@ def scene(rng):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case (the random draws of the others are still made)
     bad = 0; t0 = time.time()
     for ci in range(n_cases):
         sl, origin = scene(rng)
@@ -47,6 +48,8 @@ def main():
         opts = dict(level_steps=int(rng.choice([0, 2, 1000])), level_min_rays=0, defer_unified=int(rng.random() < 0.5), frames=int(rng.random() < 0.8))
         seed = int(rng.integers(0, 1 << 30))
         args = (K, 1e-7, np.array([thr, thr]), tir, full, single, False)
+        if only >= 0 and ci != only:
+            continue
         ref = O.trace(sp, rays.copy(), sl, *args, seed=seed, compat="matlab", final=True)
         c = Context(0)
         try:
@@ -68,7 +71,10 @@ def main():
             msg.append("scatter counts %s vs %s" % (scat.tolist(), ref.n_scat.tolist()))
         f = out[3]; fe = np.abs(f - ref.final) / np.maximum(1, np.abs(ref.final)); fe[np.isnan(f) & np.isnan(ref.final)] = 0
         if np.nanmax(fe) > 1e-4 or not np.array_equal(np.isnan(f), np.isnan(ref.final)):
-            msg.append("final rows differ by %.3g in %d rows" % (np.nanmax(fe), int((np.nan_to_num(fe, nan=1).max(axis=1) > 1e-4).sum())))
+            rows_bad = np.nonzero(np.nan_to_num(fe, nan=1).max(axis=1) > 1e-4)[0]
+            msg.append("final rows differ by %.3g in %d rows (first: row %d, columns %s)" % (np.nanmax(fe), rows_bad.size, rows_bad[0], np.nonzero(np.nan_to_num(fe[rows_bad[0]], nan=1) > 1e-4)[0].tolist()))
+            if only >= 0:
+                print("device", f[rows_bad[0]].tolist()); print("oracle", ref.final[rows_bad[0]].tolist())
         if full and len(out[0]) != len(ref.ray_interfaces):
             msg.append("record steps %d vs %d" % (len(out[0]), len(ref.ray_interfaces)))
         tag = "case %d: n=%d single=%d full=%d K=%d tir=%g thr=%g %s S=%d" % (ci, n, single, full, K, tir, thr, opts, len(sl))
