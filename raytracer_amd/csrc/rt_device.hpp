@@ -1225,55 +1225,66 @@ __device__ __forceinline__ V3 shfl_v3(V3 v, int src) { return V3{ shfl_d(v.x, sr
 __device__ __forceinline__ V3 facet_normal_wave(bool need, Rng& g, V3 indir, V3 sn, V3 sx, V3 sy, double sig, int maxiter) {
     V3 f = sn;
     const int lane = (int)(threadIdx.x & 63);
-    unsigned long long pending = __ballot(need && sig != 0 && maxiter > 0);
-    int it = 0;                      // tries of my ray that are known to have failed
+    unsigned long long want = __ballot(need && sig != 0 && maxiter > 0); // rays that still need a normal
+    int it = 0;                      // tries of my ray that are behind it
     const uint32_t idx0 = g.idx;
-    while (pending) {
-        const int np = __popcll(pending);
-        const int c = 64 / np;                                          // tries per ray this round
-        const int rank = __popcll(pending & ((1ull << lane) - 1ull));  // my ray's place among the rays still drawing
-        const bool mine = (pending >> lane) & 1ull;
-        // rank -> lane: every drawing lane sends its number to the lane of its rank
-        const int r2l = __builtin_amdgcn_ds_permute((mine ? rank : 63) << 2, mine ? lane : 0); // idle lanes all write to lane 63, which no rank < np <= 63 reads unless np == 64 (then nobody is idle)
-        const int s = lane / c, j = lane % c;
-        const bool work = s < np;
-        const int src = __shfl(r2l, work ? s : 0);
-        // the ray whose try this lane evaluates
-        const V3 rd = shfl_v3(indir, src), rn = shfl_v3(sn, src), rx = shfl_v3(sx, src), ry = shfl_v3(sy, src);
-        const double rs = shfl_d(sig, src);
-        const uint32_t r0 = (uint32_t)__shfl((int)g.c0, src), r1 = (uint32_t)__shfl((int)g.c1, src), r2 = (uint32_t)__shfl((int)g.c2, src), rstep = (uint32_t)__shfl((int)g.step, src);
-        const uint32_t ridx = (uint32_t)__shfl((int)idx0, src);
-        const int rit = __shfl(it, src);
-        const int tr = rit + j;                                        // number of the try
-        const uint32_t b = ridx + 4u * (uint32_t)tr;
-        // uniforms b .. b+3 of that ray's stream: two Philox blocks, a third if the stream stands at an odd uniform
-        uint32_t p0, p1, p2, p3, q0, q1, q2, q3, w0 = 0, w1 = 0, w2, w3;
-        const uint32_t blk = b >> 1, odd = b & 1u;
-        philox(r0, r1, r2, (rstep << 20) | (blk & 0xFFFFFu), g.k0, g.k1, p0, p1, p2, p3);
-        philox(r0, r1, r2, (rstep << 20) | ((blk + 1u) & 0xFFFFFu), g.k0, g.k1, q0, q1, q2, q3);
-        if (__ballot(odd != 0)) philox(r0, r1, r2, (rstep << 20) | ((blk + 2u) & 0xFFFFFu), g.k0, g.k1, w0, w1, w2, w3);
-        auto u53 = [](uint32_t a, uint32_t c) { return ((double)(a >> 5) * 67108864.0 + (double)(c >> 6)) * (1.0 / 9007199254740992.0); };
-        const double u1 = odd ? u53(p2, p3) : u53(p0, p1), u2 = odd ? u53(q0, q1) : u53(p2, p3);
-        const double u3 = odd ? u53(q2, q3) : u53(q0, q1), u4 = odd ? u53(w0, w1) : u53(q2, q3);
-        const double th = fabs(rs * (sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2)));
-        double st, ct; sincos(th, &st, &ct);
-        const bool out_of_range = th >= 0.5 * 3.14159265358979323846;
-        const double fmx = rs * 4 < 1 ? rs * 4 : 1;
-        const bool fail_jac = u3 * fmx > st;
-        double sp, cp; sincos(TWO_PI * u4, &sp, &cp);
-        const V3 cand = ct * rn + (st * cp) * rx + (st * sp) * ry;
-        const bool wrong = dot(rd, cand) >= 0;
-        const bool last = tr == maxiter - 1;                           // the loop ends with this try whatever it gives
-        const bool ok = work && tr < maxiter && (last || !(out_of_range || fail_jac || wrong));
-        const unsigned long long okm = __ballot(ok);
-        // back at the rays: the first good try of my group, if any
-        const unsigned long long grp = (c == 64 ? okm : (okm >> (rank * c)) & ((1ull << c) - 1ull));
-        const bool hit = mine && grp != 0;
-        const int fj = hit ? __ffsll((long long)grp) - 1 : 0;
-        const V3 got = shfl_v3(cand, mine ? rank * c + fj : lane);
-        if (hit) { f = got; it += fj + 1; }
-        else if (mine) it += c;
-        pending &= ~__ballot(hit);
+    const double fmx_own = sig * 4 < 1 ? sig * 4 : 1;
+    while (want) {
+        // Stage 1, in rounds: the polar angle of a try and the two tests that need nothing else (range, Jacobian), tried
+        // speculatively for the rays that have no such try yet.  Stage 2, once for all of them: azimuth, the normal
+        // itself and the facing test, each ray for its own first try that passed stage 1.
+        unsigned long long pending = want;
+        double t_st = 0, t_ct = 1, t_u4 = 0; bool t_last = false;
+        while (pending) {
+            const int np = __popcll(pending);
+            const int c = 64 / np;                                          // tries per ray this round
+            const int rank = __popcll(pending & ((1ull << lane) - 1ull));  // my ray's place among the rays still drawing
+            const bool mine = (pending >> lane) & 1ull;
+            // rank -> lane: every drawing lane sends its number to the lane of its rank
+            const int r2l = __builtin_amdgcn_ds_permute((mine ? rank : 63) << 2, mine ? lane : 0); // idle lanes all write to lane 63, which no rank < np <= 63 reads unless np == 64 (then nobody is idle)
+            const int s = lane / c, j = lane % c;
+            const bool work = s < np;
+            const int src = __shfl(r2l, work ? s : 0);
+            // the ray whose try this lane evaluates
+            const double rs = shfl_d(sig, src), fmx = shfl_d(fmx_own, src);
+            const uint32_t r0 = (uint32_t)__shfl((int)g.c0, src), r1 = (uint32_t)__shfl((int)g.c1, src), r2 = (uint32_t)__shfl((int)g.c2, src), rstep = (uint32_t)__shfl((int)g.step, src);
+            const uint32_t ridx = (uint32_t)__shfl((int)idx0, src);
+            const int rit = __shfl(it, src);
+            const int tr = rit + j;                                        // number of the try
+            const uint32_t b = ridx + 4u * (uint32_t)tr;
+            // uniforms b .. b+3 of that ray's stream: two Philox blocks, a third if the stream stands at an odd uniform
+            uint32_t p0, p1, p2, p3, q0, q1, q2, q3, w0 = 0, w1 = 0, w2, w3;
+            const uint32_t blk = b >> 1, odd = b & 1u;
+            philox(r0, r1, r2, (rstep << 20) | (blk & 0xFFFFFu), g.k0, g.k1, p0, p1, p2, p3);
+            philox(r0, r1, r2, (rstep << 20) | ((blk + 1u) & 0xFFFFFu), g.k0, g.k1, q0, q1, q2, q3);
+            if (__ballot(odd != 0)) philox(r0, r1, r2, (rstep << 20) | ((blk + 2u) & 0xFFFFFu), g.k0, g.k1, w0, w1, w2, w3);
+            auto u53 = [](uint32_t a, uint32_t c_) { return ((double)(a >> 5) * 67108864.0 + (double)(c_ >> 6)) * (1.0 / 9007199254740992.0); };
+            const double u1 = odd ? u53(p2, p3) : u53(p0, p1), u2 = odd ? u53(q0, q1) : u53(p2, p3);
+            const double u3 = odd ? u53(q2, q3) : u53(q0, q1), u4 = odd ? u53(w0, w1) : u53(q2, q3);
+            const double th = fabs(rs * (sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2)));
+            double st, ct; sincos(th, &st, &ct);
+            const bool out_of_range = th >= 0.5 * 3.14159265358979323846;
+            const bool fail_jac = u3 * fmx > st;
+            const bool last = tr == maxiter - 1;                           // the loop ends with this try whatever it gives
+            const bool ok = work && tr < maxiter && (last || !(out_of_range || fail_jac));
+            const unsigned long long okm = __ballot(ok);
+            // back at the rays: the first try of my group that passed, if any
+            const unsigned long long grp = (c == 64 ? okm : (okm >> (rank * c)) & ((1ull << c) - 1ull));
+            const bool hit = mine && grp != 0;
+            const int fj = hit ? __ffsll((long long)grp) - 1 : 0;
+            const int from = mine ? rank * c + fj : lane;
+            const double g_st = shfl_d(st, from), g_ct = shfl_d(ct, from), g_u4 = shfl_d(u4, from);
+            const int g_last = __shfl((int)last, from);
+            if (hit) { t_st = g_st; t_ct = g_ct; t_u4 = g_u4; t_last = g_last != 0; it += fj + 1; }
+            else if (mine) it += c;
+            pending &= ~__ballot(hit);
+        }
+        const bool mine2 = (want >> lane) & 1ull;
+        double sp, cp; sincos(TWO_PI * t_u4, &sp, &cp);
+        const V3 cand = t_ct * sn + (t_st * cp) * sx + (t_st * sp) * sy;
+        const bool wrong = dot(indir, cand) >= 0;
+        if (mine2) f = cand;
+        want &= ~__ballot(mine2 && (t_last || !wrong));                   // a try that faces the wrong way is behind the ray now: on with the next ones
     }
     if (it > 0) rng_seek(g, idx0 + 4u * (uint32_t)it);
     return f;
