@@ -185,6 +185,8 @@ RT_HD bool inbounds(const Geom& G, const BRec& first, int off, int len, V3 p) {
 } // namespace rt
 #include <cmath>
 #include <vector>
+#include <algorithm>
+#include <cstdlib>
 namespace rt {
 #if defined(__HIPCC__)
 #define RT_HOST __host__
@@ -566,7 +568,7 @@ RT_HD void generic_surface(const Geom& G, const Prm& P, V3 sp, V3 d, int six_las
 // the point.  Surfaces that fit no frame run generic_surface().  Everything is wave-uniform control flow over
 // 128-byte records read with scalar loads.
 constexpr int PREC = 16; // doubles per program record
-enum { PK_FRAME = 0, PK_PLANE = 1, PK_SPHERE = 2, PK_CYL = 3, PK_QUAD = 4, PK_GENERIC = 5, PK_TORUS = 6 };
+enum { PK_FRAME = 0, PK_PLANE = 1, PK_SPHERE = 2, PK_CYL = 3, PK_QUAD = 4, PK_GENERIC = 5, PK_TORUS = 6, PK_GROUP = 7 };
 enum { FA_AXIAL = 0, FA_RADIAL2 = 1, FA_DIST2 = 2 };
 // record word 0 (64-bit integer): bits 0-3 kind, 4-15 surface number, 16-17 number of inline range atoms,
 // 20+4j..23+4j atom j: bits 0-1 coordinate (FA_*) (bounds are exclusive; inclusive ones are stored one ulp wider);
@@ -691,6 +693,16 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
                 const bool reach = act & (disc >= 0) & (lo <= hi);
                 if (!RT_ANY(reach)) i += (int)((mlo >> 4) & 0xFFFu);
             }
+            continue;
+        }
+        if (kind == PK_GROUP) { // members of the frame that lie in a shell (radius^2 >= w7) or beyond an axial coordinate (>= w8, <= w9):
+            // a wave none of whose rays gets there before its best hit so far skips them (count in the meta word)
+            if (T.npend) frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T); // hits of queued tori count
+            const double te = h.l;
+            const double r2e = (F.a * te + 2 * F.hb) * te + F.uu;       // radius^2 is convex along the ray: the largest value is at an end
+            const double ae = F.xa + F.da * te;                          // NaN (0 * inf) fails every comparison: the ray counts as reaching
+            const bool out = (fmax(F.uu, r2e) < R.w[7]) | (fmax(F.xa, ae) < R.w[8]) | (fmin(F.xa, ae) > R.w[9]);
+            if (!RT_ANY(act & !out)) i += (int)((mlo >> 4) & 0xFFFu);
             continue;
         }
         if (kind == PK_GENERIC) {
@@ -960,10 +972,12 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
         size_t frec;
         { double w[6] = { F.c0.x, F.c0.y, F.c0.z, F.ax.x, F.ax.y, F.ax.z }; frec = put((uint64_t)PK_FRAME, w, 6); }
         double box_r2 = 0, box_lo = INFINITY, box_hi = -INFINITY; int nmem = 0;
+        struct Mem { uint64_t meta; double w[PREC - 1]; double r2min, r2max, lo, hi; };
+        std::vector<Mem> mem;
         for (int s = 0; s < S; s++) {
             if (fr[s] != (int)f) continue;
             const double* r = table + (size_t)s * ROW; const int shape = (int)r[0];
-            double w[PREC - 1]; for (int j = 0; j < PREC - 1; j++) w[j] = 0.0;
+            Mem M; double* w = M.w; for (int j = 0; j < PREC - 1; j++) w[j] = 0.0;
             uint64_t meta = (uint64_t)((uint32_t)s << 4);
             if (shape == SH_PLANE) { meta |= PK_PLANE; w[0] = dt(sub(mk(r + 2), F.c0), F.ax); w[1] = sg[s]; }
             else if (shape == SH_CYL) { meta |= PK_CYL; w[0] = r[8]; w[1] = r[8] * r[8]; }
@@ -980,9 +994,87 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
                 const double pad = 1e-9 * (fabs(alo) + fabs(ahi) + rr);
                 w[12] = alo - pad; w[13] = ahi + pad; w[14] = ri2 * (1 - 1e-9);
             }
-            put(meta, w, PREC - 1);
-            double r2, lo, hi; member_extent(meta, w, program_box(s, F), r2, lo, hi);
-            box_r2 = fmax(box_r2, r2); box_lo = fmin(box_lo, lo); box_hi = fmax(box_hi, hi); nmem++;
+            M.meta = meta;
+            member_extent(meta, w, program_box(s, F), M.r2max, M.lo, M.hi);
+            // smallest radius^2 a hit on this member can have: its shape over [lo, hi], raised by the lower end of an inline radial range
+            {
+                const uint32_t kind = (uint32_t)meta & 15u;
+                auto quad_min = [&](double al, double ga, double pa, double Rp) { // rho^2 = -(ga x^2 + pa x + Rp) / al over [M.lo, M.hi]
+                    if (al == 0) return 0.0;
+                    const double qa = -ga / al, qb = -pa / al, qc = -Rp / al;
+                    double m = INFINITY;
+                    const double ends[2] = { M.lo, M.hi };
+                    for (double x : ends) { if (std::isinf(x)) return 0.0; m = fmin(m, (qa * x + qb) * x + qc); }
+                    if (qa > 0) { const double xv = -qb / (2 * qa); if (xv >= M.lo && xv <= M.hi) m = fmin(m, (qa * xv + qb) * xv + qc); }
+                    return m;
+                };
+                double r2 = 0.0;
+                if (kind == PK_CYL) r2 = w[1];
+                else if (kind == PK_SPHERE) r2 = quad_min(1.0, 1.0, -2 * w[0], w[2]);
+                else if (kind == PK_QUAD) r2 = quad_min(w[0], w[1], w[2], w[3]);
+                else if (kind == PK_TORUS) { const double ri = fmax(fabs(w[1]) - fabs(w[2]), 0.0); r2 = ri * ri; }
+                const uint32_t na = (uint32_t)(meta >> 16) & 3u;
+                for (uint32_t j = 0; j < na; j++) if (((uint32_t)(meta >> (20 + 4 * j)) & 3u) == FA_RADIAL2) r2 = fmax(r2, w[6 + 3 * j]);
+                M.r2min = (r2 > 0 && !std::isnan(r2)) ? r2 : 0.0;
+            }
+            if (M.lo > M.hi) continue; // bounds that nothing satisfies (e.g. z > 120 & z < -20): no record, the surface can never be hit
+            mem.push_back(M);
+            box_r2 = fmax(box_r2, M.r2max); box_lo = fmin(box_lo, M.lo); box_hi = fmax(box_hi, M.hi);
+        }
+        // Order: the members in list order, except those far out - radially (a shell) or along the axis (above, below) -
+        // which go behind GROUP records, nested from the inside out.  "Far out" is measured against the median extent of
+        // the frame's members, so that a group is skipped by rays that stay where most of the geometry is.
+        {
+            auto median = [](std::vector<double> v) { if (v.empty()) return (double)NAN; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            std::vector<int> core, shell, above, below;
+            std::vector<char> used(mem.size(), 0);
+            const bool groups_on = frames_on && getenv("RT_NO_GROUPS") == nullptr;
+            if (groups_on && mem.size() >= 6) {
+                std::vector<double> v; for (const Mem& M : mem) v.push_back(M.r2max);
+                const double med_r2 = median(v);
+                for (size_t j = 0; j < mem.size(); j++) if (mem[j].r2min > 0 && mem[j].r2min >= med_r2 * (1 + 1e-9)) { shell.push_back((int)j); used[j] = 1; }
+                if (shell.size() < 2) { for (int j : shell) used[j] = 0; shell.clear(); }
+                v.clear(); for (size_t j = 0; j < mem.size(); j++) if (!used[j]) v.push_back(mem[j].hi);
+                const double med_hi = median(v);
+                for (size_t j = 0; j < mem.size(); j++) if (!used[j] && std::isfinite(mem[j].lo) && mem[j].lo > med_hi) { above.push_back((int)j); used[j] = 1; }
+                if (above.size() < 2) { for (int j : above) used[j] = 0; above.clear(); }
+                v.clear(); for (size_t j = 0; j < mem.size(); j++) if (!used[j]) v.push_back(mem[j].lo);
+                const double med_lo = median(v);
+                for (size_t j = 0; j < mem.size(); j++) if (!used[j] && std::isfinite(mem[j].hi) && mem[j].hi < med_lo) { below.push_back((int)j); used[j] = 1; }
+                if (below.size() < 2) { for (int j : below) used[j] = 0; below.clear(); }
+            }
+            for (size_t j = 0; j < mem.size(); j++) if (!used[j]) core.push_back((int)j);
+            for (int j : core) { put(mem[j].meta, mem[j].w, PREC - 1); nmem++; }
+            // kind 0: shell (key = r2min, ascending), 1: above (key = lo, ascending), 2: below (key = hi, descending)
+            auto chain = [&](std::vector<int>& g, int kind) {
+                auto key = [&](int j) { return kind == 0 ? mem[j].r2min : (kind == 1 ? mem[j].lo : -mem[j].hi); };
+                std::stable_sort(g.begin(), g.end(), [&](int a_, int b_) { return key(a_) < key(b_); });
+                // a new (nested) group wherever the key grows noticeably and at least two members remain
+                std::vector<size_t> starts;
+                double span = 0; { double a_ = INFINITY, b_ = -INFINITY; for (const Mem& M : mem) { if (std::isfinite(M.lo)) a_ = fmin(a_, M.lo); if (std::isfinite(M.hi)) b_ = fmax(b_, M.hi); } if (b_ > a_) span = b_ - a_; }
+                double gkey = 0;
+                for (size_t p = 0; p < g.size(); p++) {
+                    const double k = key(g[p]);
+                    const bool first = p == 0, grows = !first && (kind == 0 ? k > 1.2 * gkey : k - gkey > 0.05 * span);
+                    if ((first || grows) && g.size() - p >= 2) { starts.push_back(p); gkey = k; }
+                }
+                size_t si = 0;
+                for (size_t p = 0; p < g.size(); p++) {
+                    if (si < starts.size() && starts[si] == p) {
+                        const size_t later_groups = starts.size() - si - 1, count = (g.size() - p) + later_groups;
+                        double w[PREC - 1]; for (int j = 0; j < PREC - 1; j++) w[j] = 0.0;
+                        const double k = key(g[p]);
+                        w[6] = -INFINITY; w[7] = -INFINITY; w[8] = INFINITY;
+                        if (kind == 0) w[6] = k * (1 - 1e-9) - 1e-12;
+                        else if (kind == 1) w[7] = k - 1e-9 * (1 + fabs(k));
+                        else w[8] = -k + 1e-9 * (1 + fabs(k));
+                        put((uint64_t)PK_GROUP | ((uint64_t)count << 4), w, PREC - 1); nmem++;
+                        si++;
+                    }
+                    put(mem[g[p]].meta, mem[g[p]].w, PREC - 1); nmem++;
+                }
+            };
+            chain(shell, 0); chain(above, 1); chain(below, 2);
         }
         if (nmem < 4096 && !(std::isinf(box_r2) && std::isinf(box_lo) && std::isinf(box_hi)) && !std::isnan(box_r2)) { // bounding box of the frame's members, a little wider than computed
             uint64_t meta = (uint64_t)PK_FRAME | ((uint64_t)nmem << 4) | (1ull << 16);

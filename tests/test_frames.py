@@ -15,7 +15,7 @@ from oracle import oracle as O
 from raytracer_amd import geometries as G
 from raytracer_amd import table as T
 
-KINDS = ("FRAME", "PLANE", "SPHERE", "CYL", "QUAD", "GENERIC", "TORUS")
+KINDS = ("FRAME", "PLANE", "SPHERE", "CYL", "QUAD", "GENERIC", "TORUS", "GROUP")
 
 
 def program(sl, frames=True):
@@ -30,15 +30,31 @@ def test_program_of_the_jar_geometry():
     sl = G.create_arbc_geometry(G.sbc_full_mc_specs())
     pr = program(sl)
     c = Counter(r["kind"] for r in pr)
-    assert c["FRAME"] == 2 and c["GENERIC"] == 0 and c["TORUS"] == 4 and c["CYL"] == 14 and c["PLANE"] == 11 and c["SPHERE"] == 4 and c["QUAD"] == 6
-    assert sorted(r["surf"] for r in pr if r["kind"] != "FRAME") == list(range(39))  # every surface exactly once
+    # 'reflector/diffuser strip cone' (surface 31) is bounded by z > 120 & z < -20: nothing satisfies that, it gets no record
+    assert c["FRAME"] == 2 and c["GENERIC"] == 0 and c["TORUS"] == 4 and c["CYL"] == 14 and c["PLANE"] == 11 and c["SPHERE"] == 4 and c["QUAD"] == 5
+    assert sorted(r["surf"] for r in pr if r["kind"] not in ("FRAME", "GROUP")) == [s_ for s_ in range(39) if s_ != 31]  # every other surface exactly once
     assert sum(1 for r in pr if r["residual"]) <= 4
     assert all(r["kind"] == "GENERIC" for r in program(sl, frames=False)) and len(program(sl, frames=False)) == 39
     # bounding boxes of the frames' members (a wave skips a frame nobody can reach before its best hit): the z frame holds
     # everything up to the pressure vessel (radius 30, from z = -20 up), the camera frame the can around the viewport
     fr = [r for r in pr if r["kind"] == "FRAME"]
-    assert [r["surf"] for r in fr] == [22, 17] and all(r["natoms"] & 1 for r in fr)   # member counts, "has box" flag
+    assert all(r["natoms"] & 1 for r in fr)   # "has box" flag
     assert abs(np.sqrt(fr[0]["words"][7]) - 30) < 1e-6 and abs(fr[0]["words"][8] + 20) < 1e-6 and np.isinf(fr[0]["words"][9])
+    # GROUP records: what lies far out in a frame goes behind a test that lets a wave skip it.  In the z frame: the shell
+    # beyond radius 12 (reflector cylinder and its cone, then the pressure vessel walls nested inside it) and what lies
+    # high up (the outer domes, then the vessel heads above z = 100); counts include nested GROUP records
+    zf = pr[1:1 + fr[0]["surf"]]
+    assert fr[0]["surf"] == len(zf) and pr[1 + fr[0]["surf"]]["kind"] == "FRAME"
+    groups = [(i, r) for i, r in enumerate(zf) if r["kind"] == "GROUP"]
+    def inside(i, r):
+        return {m["surf"] for m in zf[i + 1:i + 1 + r["surf"]] if m["kind"] != "GROUP"}
+    shells = [(i, r) for i, r in groups if r["words"][7] > 0]
+    assert abs(shells[0][1]["words"][7] - 144) < 1e-3 and inside(*shells[0]) == {29, 30, 34, 35}
+    assert abs(shells[1][1]["words"][7] - 841) < 1e-2 and inside(*shells[1]) == {34, 35}
+    above = [(i, r) for i, r in groups if np.isfinite(r["words"][8])]
+    assert inside(*above[0]) == {6, 7, 36, 37} and abs(above[-1][1]["words"][8] - 100) < 1e-6 and inside(*above[-1]) == {36, 37}
+    first_group = groups[0][0]
+    assert {m["surf"] for m in zf[:first_group]} == {0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 32, 33, 38}   # the core, in list order, comes first
     g = G.sbc_full_mc_specs()
     assert abs(np.sqrt(fr[1]["words"][7]) - g.vp_flange_rad) < 1e-6 and fr[1]["words"][8] < 0 < fr[1]["words"][9] < 2 * g.vp_can_OAL
 
