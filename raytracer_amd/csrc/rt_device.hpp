@@ -1600,6 +1600,21 @@ template <int CF = -1, int UNI = 0> RT_HD void bounce_phys(const Geom& G, const 
     b.fa = b.refr.s0 > P.thrA; b.fb = b.refl.s0 > P.thrB; // :518-519
 }
 
+// Does the ray scatter in the bulk (Rayleigh) before it reaches the surface of its nearest hit?  The draw and the
+// comparison of python/RayTracer2.py:409-417 exactly as bounce_phys_single() / bounce_phys() make them (same stream
+// position: a diffuse surface has drawn two uniforms before).  Used by the level path to sort rays into launches.
+RT_HD bool level_ray_scatters(const Geom& G, const Prm& P, int64_t ray_id, uint32_t hash, int k, const Hit& h) {
+    if (h.surf < 0) return false;
+    const double* row = G.surf + h.surf * ROW;
+    const bool in = h.orient < 0;
+    const double rayl1 = in ? row[21] : row[20];
+    if (!(rayl1 < INFINITY)) return false;
+    Rng g; rng_init(g, P.key0, P.key1, ray_id, hash, k);
+    if ((int)row[1] == ST_DIFFUSE) { (void)rng_uniform(g); (void)rng_uniform(g); }
+    const double l_bulk = -rayl1 * log(rng_uniform(g));
+    return !(h.l <= l_bulk);
+}
+
 // ---------------------------------------------------------------------------------------------- single-child step, tallies only
 // The same step as bounce_phys<FLAG_SINGLE>() for runs that keep neither records nor final rows: the dice of
 // python/RayTracer2.py:458-467 needs only the two children's intensities, so they are computed first and only the
@@ -1613,7 +1628,9 @@ struct LeanBounce {
 // UNI = 1: the kernel pass that sees nothing but rays ending on UNIFIED surfaces carries the rough-surface loop in
 // line, with the register budget that needs; UNI = 2: the pass that has put those rays aside carries no UNIFIED code at
 // all; UNI = 0 (everywhere else): out of line.
-template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b, bool act = true) {
+// NORAY (with UNI = 2): the caller has also put aside the rays that scatter in the bulk before they reach their surface
+// (level_ray_scatters() below, the same arithmetic): every ray that comes here scatters on its surface, no Rayleigh code.
+template <int UNI = 0, bool NORAY = false> RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b, bool act = true) {
     Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
     b.scat = 0; b.surf_sc = 0; b.fa = 0; b.smix_next = 0; b.six_next = 0; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = 0;
@@ -1639,7 +1656,7 @@ template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P
     b.scat = 1;
     double l_bulk = INFINITY;
     if (rayl1 < INFINITY) l_bulk = -rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
-    const bool surf_sc = h.l <= l_bulk;
+    const bool surf_sc = (UNI == 2 && NORAY) ? true : (h.l <= l_bulk);
     b.surf_sc = surf_sc;
     const bool uni_sc = UNI != 2 && surf_sc && st == ST_UNIFIED, nor_sc = surf_sc && !uni_sc;
     double l = h.l;
@@ -1682,7 +1699,7 @@ template <int UNI = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P
             if (goodcut) ch.d = (c.sin_t >= 1) ? -ny : (-c.cos_t) * c.n - c.sin_t * ny;
         }
         ch.s0 *= f; ch.s1 *= f; ch.s2 *= f; ch.s3 *= f;
-    } else {
+    } else if constexpr (!(UNI == 2 && NORAY)) {
         Ray10 r;
         bool ray_sc = true;
         if constexpr (UNI != 2) {

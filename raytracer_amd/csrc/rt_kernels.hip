@@ -460,7 +460,8 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
     }
 }
 
-// PASS 0: every ray of the segment.  PASS 1: rays ending on a UNIFIED surface are only listed (KArgs::defer).
+// PASS 0: every ray of the segment.  PASS 1: rays ending on a UNIFIED surface, and rays that scatter in the bulk before
+// they reach theirs, are only listed (KArgs::defer); the others are worked through from a dense list.
 // PASS 2: the listed rays, children appended behind those of pass 1; for CF == FLAG_SINGLE (tallies only) the wave
 // works through the UNIFIED model together (unified_wave), otherwise every lane runs it in line.
 // PASS 3: PASS 0 for a geometry without UNIFIED surfaces (no such code in the kernel).
@@ -485,13 +486,21 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     KArgs t = a; t.rows_lds = 1; // tally_add(): row 0 of the LDS image is step k
     const int64_t seg0 = (int64_t)blockIdx.x * a.seg_cap;
     int64_t n = seg0 + (int64_t)(PASS == 2 ? a.defer_n[blockIdx.x] : a.seg_in[blockIdx.x]);
-    const bool listed = PASS == 2 || (PASS == 1 && a.defer != nullptr);
-    if (PASS == 1 && listed) { // sort the segment's rays into the two lists; this launch then takes the dense one
+    constexpr bool listed = PASS == 2 || PASS == 1;
+    if constexpr (PASS == 1) { // sort the segment's rays into the two lists; this launch then takes the dense one
         for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
             const int64_t idx = base + lane_id();
             if (idx < n) {
                 const int so = a.hit_so[idx];
-                if (so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED) a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
+                bool heavy = so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED;
+                if (!heavy && so >= 0) { // bulk scatter before the surface: the other launch has the Rayleigh code
+                    const double* row = s_surf + (so >> 2) * ROW;
+                    if ((((so & 3) - 1) < 0 ? row[21] : row[20]) < INFINITY) {
+                        Hit h; h.l = a.hit_l[idx]; h.surf = so >> 2; h.orient = (so & 3) - 1;
+                        heavy = level_ray_scatters(G, P, a.in_i[idx], (uint32_t)a.in_m[idx], k, h);
+                    }
+                }
+                if (heavy) a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
                 else a.dense[seg0 + (int64_t)wave_alloc_lds(&s_cnt[4])] = (uint32_t)(idx - seg0);
             }
         }
@@ -517,7 +526,9 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
             if (act) atomicAdd(&s_cnt[0], 1u);
             if constexpr (CF == FLAG_SINGLE) { // tallies only: one child, built after the dice
                 LeanBounce b;
-                bounce_phys_single<PASS == 2 ? 1 : (PASS == 1 ? 2 : 0)>(G, P, q, h, b, act);
+                // PASS 1 working through its list: neither UNIFIED surfaces nor bulk scatters come here (the sort above decided)
+                if constexpr (PASS == 1) bounce_phys_single<2, true>(G, P, q, h, b, act);
+                else bounce_phys_single<PASS == 2 ? 1 : (PASS == 3 ? 2 : 0)>(G, P, q, h, b, act);
                 if (!act) {}
                 else if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
                 else {
@@ -890,7 +901,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     DevBuf b_hl, b_hso, b_seg, b_defer;
     const int nseg_max = ctx->n_cu * ctx->seg_per_cu;
     // geometry with UNIFIED surfaces: the rays that end on them get a physics launch of their own (k_level_phys PASS 1 + 2)
-    const bool defer = level && ctx->has_unified && ctx->defer_unified;
+    const bool defer = level && ctx->has_unified && ctx->defer_unified; // (a launch of their own for bulk scatters alone did not pay: SBC light collection 6.1e9 -> 5.6e9)
     if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 3 * (size_t)nseg_max)); }
     if (defer) CK(dev_alloc(ctx, b_defer, 2 * 4 * (size_t)q_cap));
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
@@ -921,7 +932,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     // k_level_phys variants: 3 = geometry without UNIFIED surfaces; 1 + 2 = those rays in a launch of their own; 0 = one launch
     const bool nu = !ctx->has_unified;
     void (*kphys)(const KArgs); void (*kphys2)(const KArgs) = nullptr;
-#define RT_PICK(CF_) { if (nu) kphys = k_level_phys<CF_, (CF_) == FLAG_SINGLE ? 1 : 3>; else if (defer) { kphys = k_level_phys<CF_, 1>; kphys2 = k_level_phys<CF_, 2>; } else kphys = k_level_phys<CF_, 0>; }
+#define RT_PICK(CF_) { if (defer) { kphys = k_level_phys<CF_, 1>; kphys2 = k_level_phys<CF_, 2>; } else if (nu) kphys = k_level_phys<CF_, 3>; else kphys = k_level_phys<CF_, 0>; }
     if (!single) { if (out) RT_PICK(FLAG_FULL | FLAG_FINAL) else RT_PICK(0) }
     else { if (out) RT_PICK(FLAG_SINGLE | FLAG_FULL | FLAG_FINAL) else RT_PICK(FLAG_SINGLE) }
 #undef RT_PICK
