@@ -173,7 +173,9 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
  * reference's formulas for every surface instead of the frame program), "refill_min" (idle lanes per wave that
  * trigger a refill of the persistent kernel, default 4), "blocks_per_cu" (0 = occupancy query), "nodice_chunk" (rays
  * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "match_max_level" (rt_match_endpoints: deepest level of
- * the search tree, default 10), "release_workspace" (free the pooled device buffers). */
+ * the search tree, default 10), "stream_overlap" (0: record streaming copies and calls the sink between the kernels of
+ * two chunks, as up to r1k), "stream_stage_gb" (bytes of records per chunk handed to a record sink, default 2; two
+ * pinned host buffers of that size are kept), "release_workspace" (free the pooled device buffers and those two). */
 int rt_set_option(rt_ctx* ctx, const char* key, double value);
 
 /* Record streaming (no reference counterpart: the reference keeps every rayInterfaces array in
@@ -181,8 +183,11 @@ int rt_set_option(rt_ctx* ctx, const char* key, double value);
  * rays as soon as that chunk is traced instead of accumulating them: n records in device order with the same ordering
  * keys as rt_result_records (parent = index within this call of the sink, or -1), for the rays
  * [first_ray_id, first_ray_id + n_rays) - in single-child mode all interactions of those rays.  The pointers are valid
- * during the call only.  Chunk size follows "workspace_gb" (single-child) / "nodice_chunk" (ray splitting).  A non-zero
- * return stops the trace (rt_trace returns -4).  sink = NULL restores accumulation. */
+ * during the call only.  The records of a chunk are packed on the device and copied into one of two pinned host
+ * stages on a second stream; the sink is called on rt_trace's thread for chunk c-1 while chunk c is being copied, and
+ * chunk c+1 is traced under the same copy.  Chunk size: "stream_stage_gb" worth of records (single-child: that many
+ * bytes / (408 * max_scat) rays) / "nodice_chunk" (ray splitting).  A non-zero return stops the trace (rt_trace
+ * returns -4).  sink = NULL restores accumulation. */
 typedef int (*rt_record_sink)(void* user, int64_t n, const double* rec /*[n][RT_REC_COLS]*/, const int32_t* step, const int64_t* ray_id,
                               const int64_t* parent, const int32_t* flags, int64_t first_ray_id, int64_t n_rays);
 int rt_set_record_sink(rt_ctx* ctx, rt_record_sink sink, void* user);

@@ -605,6 +605,15 @@ __global__ void k_rec_to_rows(const double* rec, int64_t cap, int64_t n, double*
     int64_t i = t / REC; int f = (int)(t % REC);
     rows[t] = rec[(int64_t)f * cap + i];
 }
+// one chunk's records as the record sink sees them, in one block of memory: rows [n][REC] | ray [n] | parent [n] | step [n] | flags [n]
+__global__ void k_rec_pack(const double* rec, int64_t cap, int64_t n, const int32_t* step, const int32_t* flags, const int64_t* ray, const int64_t* parent, char* out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * REC) { int64_t i = t / REC; int f = (int)(t % REC); ((double*)out)[t] = rec[(int64_t)f * cap + i]; }
+    if (t < n) {
+        int64_t* o_ray = (int64_t*)(out + (size_t)n * REC * 8); int64_t* o_par = o_ray + n; int32_t* o_step = (int32_t*)(o_par + n); int32_t* o_fl = o_step + n;
+        o_ray[t] = ray[t]; o_par[t] = parent[t]; o_step[t] = step[t]; o_fl[t] = flags[t];
+    }
+}
 __global__ void k_gen_point(KArgs a, int64_t n, double* start, double* rays) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -647,6 +656,10 @@ struct rt_ctx {
     double* d_fin_user = nullptr; int64_t fin_user_rows = 0; // rt_set_final_rows_device: final rows stay in the caller's device buffer
     std::vector<std::pair<void*, size_t>> pool; // cached device buffers (see DevBuf)
     rt_record_sink sink = nullptr; void* sink_user = nullptr; // records leave chunk by chunk instead of accumulating
+    // record streaming: two pinned host stages, a copy stream; the D2H copy of chunk c runs under the sink call of chunk c-1 and the kernels of chunk c+1
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2] = { nullptr, nullptr }, ev_copied[2] = { nullptr, nullptr };
+    char* pin[2] = { nullptr, nullptr }; size_t pin_bytes[2] = { 0, 0 };
+    bool stream_overlap = true; size_t stream_stage_bytes = (size_t)2 << 30;
     double kernel_ms = 0; int n_launches = 0;
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
@@ -684,6 +697,8 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     const char* sc = getenv("RT_SEG_PER_CU"); if (sc && atoi(sc) > 0 && atoi(sc) <= 64) ctx->seg_per_cu = atoi(sc);
     const char* hb = getenv("RT_HIT_BLOCKS_PER_CU"); if (hb && atoi(hb) >= 0) ctx->hit_blocks_per_cu = atoi(hb);
     const char* pb = getenv("RT_PHYS_BLOCKS_PER_CU"); if (pb && atoi(pb) >= 0) ctx->phys_blocks_per_cu = atoi(pb);
+    const char* so = getenv("RT_STREAM_OVERLAP"); if (so) ctx->stream_overlap = atoi(so) != 0;
+    const char* sg = getenv("RT_STREAM_STAGE_GB"); if (sg && atof(sg) > 0) ctx->stream_stage_bytes = (size_t)(atof(sg) * (double)(1ull << 30));
     *out = ctx; return 0;
 }
 
@@ -692,6 +707,8 @@ extern "C" void rt_free(rt_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog); hipFree(ctx->d_cam); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps); hipFree(ctx->d_lvl);
     for (auto& pb : ctx->pool) hipFree(pb.first);
+    for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); if (ctx->ev_ready[s]) hipEventDestroy(ctx->ev_ready[s]); if (ctx->ev_copied[s]) hipEventDestroy(ctx->ev_copied[s]); }
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -711,7 +728,12 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "blocks_per_cu") ctx->blocks_per_cu = (int)value;
     else if (k == "nodice_chunk") ctx->nodice_chunk = (int64_t)value;
     else if (k == "lds_budget_kb") ctx->lds_budget = (size_t)(value * 1024);
-    else if (k == "release_workspace") { hipSetDevice(ctx->device); for (auto& pb : ctx->pool) hipFree(pb.first); ctx->pool.clear(); }
+    else if (k == "release_workspace") {
+        hipSetDevice(ctx->device); for (auto& pb : ctx->pool) hipFree(pb.first); ctx->pool.clear();
+        for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); ctx->pin[s] = nullptr; ctx->pin_bytes[s] = 0; }
+    }
+    else if (k == "stream_overlap") ctx->stream_overlap = value != 0;
+    else if (k == "stream_stage_gb") { if (!(value > 0)) { ctx->err = "rt_set_option: stream_stage_gb must be positive"; return -1; } ctx->stream_stage_bytes = (size_t)(value * (double)(1ull << 30)); }
     else if (k == "frames") ctx->use_frames = value != 0;
     else if (k == "level_steps") ctx->level_steps = (int)value;
     else if (k == "level_min_rays") ctx->level_min_rays = (int64_t)value;
@@ -875,8 +897,11 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     const size_t W = ctx->workspace_bytes;
     const size_t rec_bytes = (size_t)REC * 8 + 4 + 8 + 8 + 4;
     int64_t chunk = n, rec_cap = 0, q_cap = 0;
+    // records that stream to a sink: the chunk's records + two packed copies of them (one in flight to the host, one being filled), each at most one stage
+    const bool piped = full && ctx->sink && ctx->stream_overlap;
+    const size_t Wrec = piped ? std::min(W / 3, ctx->stream_stage_bytes) : W;
     if (single) {
-        if (full) { chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(W / (rec_bytes * (size_t)K)))); rec_cap = chunk * K; }
+        if (full) { chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(Wrec / (rec_bytes * (size_t)K)))); rec_cap = chunk * K; }
         if (mode == 0 && !d_soa) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (13 * 8 * 2))));
         if (wantfin) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (FIN * 8))));
         if (prm->follow_threshold[1] < 0) q_cap = chunk * K; // degenerate: reflected child followed as well
@@ -894,7 +919,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         const size_t per_q = 2 * ((size_t)QD * 8 + QI * 8 + QM * 4) + 12 + 8;
         q_cap = std::max<int64_t>(std::min<int64_t>(1024 * chunk, (int64_t)(W / per_q)), std::max<int64_t>(4 * chunk, 1 << 16));
         q_cap += (int64_t)ctx->n_cu * ctx->seg_per_cu; // segments of the level path round the capacity up
-        if (full) rec_cap = std::max<int64_t>((int64_t)(W / rec_bytes), 1 << 16), rec_cap = std::min<int64_t>(rec_cap, (int64_t)1 << 31);
+        if (full) rec_cap = std::max<int64_t>((int64_t)(Wrec / rec_bytes), 1 << 16), rec_cap = std::min<int64_t>(rec_cap, (int64_t)1 << 31);
     }
     if (full && rec_cap < chunk) { rec_cap = chunk; }
 
@@ -913,6 +938,30 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         CK(dev_alloc(ctx, b_rpar, 8 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rflag, 4 * (size_t)rec_cap));
     }
     if (wantfin && !fin_dev) CK(dev_alloc(ctx, b_fin, (size_t)FIN * 8 * (size_t)chunk));
+    struct Stage { DevBuf dev; int64_t nrec = 0, first = 0, m = 0; bool pending = false; } stg[2];
+    if (piped) {
+        const size_t stage_bytes = rec_bytes * (size_t)rec_cap;
+        if (!ctx->copy_stream) CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int s = 0; s < 2; s++) {
+            if (!ctx->ev_ready[s]) CK(hipEventCreateWithFlags(&ctx->ev_ready[s], hipEventDisableTiming));
+            if (!ctx->ev_copied[s]) CK(hipEventCreateWithFlags(&ctx->ev_copied[s], hipEventDisableTiming));
+            CK(dev_alloc(ctx, stg[s].dev, stage_bytes));
+            if (ctx->pin_bytes[s] < stage_bytes) {
+                if (ctx->pin[s]) { CK(hipHostFree(ctx->pin[s])); ctx->pin[s] = nullptr; ctx->pin_bytes[s] = 0; }
+                CK(hipHostMalloc((void**)&ctx->pin[s], stage_bytes, hipHostMallocDefault)); ctx->pin_bytes[s] = stage_bytes;
+            }
+        }
+    }
+    // hands the records of the chunk in stage s to the sink, once their copy has landed
+    auto drain = [&](int s) -> int {
+        if (!stg[s].pending) return 0;
+        stg[s].pending = false;
+        if (hipEventSynchronize(ctx->ev_copied[s]) != hipSuccess) { ctx->err = "rt_trace: record copy failed"; return -1; }
+        const int64_t nr = stg[s].nrec; char* h = ctx->pin[s];
+        int64_t* h_ray = (int64_t*)(h + (size_t)nr * REC * 8); int64_t* h_par = h_ray + nr; int32_t* h_step = (int32_t*)(h_par + nr); int32_t* h_fl = h_step + nr;
+        if (ctx->sink(ctx->sink_user, nr, (const double*)h, h_step, h_ray, h_par, h_fl, stg[s].first, stg[s].m) != 0) { ctx->err = "rt_trace: the record sink asked to stop"; return -4; }
+        return 0;
+    };
 
     KArgs a; memset(&a, 0, sizeof a);
     a.surf = ctx->d_surf; a.S = S; a.recs = ctx->d_recs; a.smeta = ctx->d_smeta;
@@ -1049,7 +1098,23 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             CK(hipMemsetAsync(ctx->d_counters, 0, 16, ctx->stream)); // head, tail (records keep counting)
         }
         if (rc) break;
-        if (full) {
+        if (piped) {
+            unsigned long long nrec = 0;
+            CK(hipMemcpyAsync(&nrec, ctx->d_counters + 2, 8, hipMemcpyDeviceToHost, ctx->stream)); CK(hipStreamSynchronize(ctx->stream));
+            const int s = (int)((off / chunk) & 1); // free: its last chunk was drained while the previous one was copied
+            if (nrec) {
+                hipLaunchKernelGGL(k_rec_pack, dim3((unsigned)((nrec * REC + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_rec.p, rec_cap, (int64_t)nrec,
+                                   (const int32_t*)b_rstep.p, (const int32_t*)b_rflag.p, (const int64_t*)b_rray.p, (const int64_t*)b_rpar.p, (char*)stg[s].dev.p);
+                CK(hipGetLastError());
+                CK(hipEventRecord(ctx->ev_ready[s], ctx->stream));
+                CK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_ready[s], 0));
+                CK(hipMemcpyAsync(ctx->pin[s], stg[s].dev.p, rec_bytes * (size_t)nrec, hipMemcpyDeviceToHost, ctx->copy_stream));
+                CK(hipEventRecord(ctx->ev_copied[s], ctx->copy_stream));
+                stg[s].nrec = (int64_t)nrec; stg[s].first = prm->ray_id_base + off; stg[s].m = m; stg[s].pending = true;
+            }
+            rc = drain(s ^ 1); // the previous chunk goes to the sink while this one is copied; the next one is traced under the same copy
+            if (rc) break;
+        } else if (full) {
             unsigned long long nrec = 0;
             CK(hipMemcpy(&nrec, ctx->d_counters + 2, 8, hipMemcpyDeviceToHost));
             if (nrec) {
@@ -1076,6 +1141,10 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (wantfin && !fin_dev) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));
     }
     hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(ev2); hipEventDestroy(ev3);
+    if (piped) {
+        for (int s = 0; s < 2 && rc == 0; s++) { const int t = (int)(((n + chunk - 1) / chunk + s) & 1); rc = drain(t); } // older stage first
+        hipStreamSynchronize(ctx->copy_stream); // nothing of this call is in flight when its buffers go back to the pool
+    }
     if (rc) return rc;
     // ---- tallies and the reference's step bookkeeping (RayTracer2.py:266-270, 405-407, 542)
     ctx->table.assign(telems, 0.0); std::vector<unsigned long long> st(2 * (size_t)K);

@@ -114,6 +114,35 @@ def test_record_streaming_npz_shards(tmp_path):
             assert np.array_equal(got_idx[o1], ri.ray_index[o2]) and np.allclose(got_l[o1], ri.distance_traveled[o2], rtol=1e-8, atol=1e-8)  # the chunks take the persistent kernel, the whole run the level kernels
 
 
+def test_record_streaming_overlapped_copy_hands_over_the_same_chunks():
+    """the copy of one chunk's records runs under the sink call of the chunk before and the kernels of the chunk after
+    (two pinned stages): the sink sees what it sees when copy and sink run between the kernels, call for call"""
+    from raytracer_amd.RayTracer2 import Context, RayTracer2
+    sl, origin = cases.coaxial_scene(4)
+    sp, rays = cases.isotropic_rays(20011, 45, origin=tuple(origin), polarized=True)
+    args = (10, 1e-7, 1e-5, -1, True, True, False)
+
+    def run(overlap, workspace_gb):
+        calls = []
+        c = Context(0)
+        try:
+            c.set_option("workspace_gb", workspace_gb); c.set_option("stream_overlap", overlap)
+            out = RayTracer2(sp, rays.copy(), sl, *args, seed=9, compat="matlab", ctx=c,
+                             record_sink=lambda chunk, first, n, ris: calls.append((chunk, first, n, [dict(vars(r)) for r in ris])))
+        finally:
+            c.close()
+        return out, calls
+    out_a, a = run(1, 0.03)   # overlapped: a third of the workspace per stage
+    out_b, b = run(0, 0.01)   # serial, same chunk size
+    assert len(a) == len(b) >= 6 and np.allclose(out_a[1], out_b[1], rtol=1e-9, atol=1e-9)  # tallies: float atomics, order varies
+    assert [x[:3] for x in a] == [x[:3] for x in b] and [x[0] for x in a] == list(range(len(a)))
+    for (_, _, _, ra), (_, _, _, rb) in zip(a, b):
+        assert len(ra) == len(rb)
+        for da, db in zip(ra, rb):
+            for f in da:
+                assert np.array_equal(da[f], db[f], equal_nan=True), f
+
+
 @pytest.mark.parametrize("params,n_in,n_med", [((.2, .8, .2, .3, .1), 1.5, 1.0), ((.05, .5, .3, .2, .05), np.inf, 1.5), ((0, 0, .25, .5, .1), np.inf, 1.5),
                                                ((.6, .3, .5, .1, .1), 1.3, 1.5)])
 def test_unified_rays_get_their_own_launch(params, n_in, n_med):
