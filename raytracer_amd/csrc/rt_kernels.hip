@@ -81,7 +81,8 @@ struct KArgs {
     const uint32_t* seg_in; uint32_t* seg_out; int64_t seg_cap;
     int64_t seg_fill;       // k_level_init: rays per segment at the start (== seg_cap unless rays split and segments need room to grow)
     // rays that end on a UNIFIED surface are put aside by the first physics pass (their offsets within the segment,
-    // defer[b * seg_cap + j], j < defer_n[b]) and taken by a second launch in which every lane runs the rough-surface loop
+    // defer[b * seg_cap + j], j < defer_n[2 b]) and taken by a second launch in which every lane runs the rough-surface loop;
+    // rays that scatter in the bulk go there too, listed from the other end (defer[(b + 1) * seg_cap - 1 - j], j < defer_n[2 b + 1])
     uint32_t* defer; uint32_t* defer_n;
     uint32_t* dense;        // pass 1: the other rays of the segment, listed the same way, so that its waves are full
 };
@@ -467,7 +468,7 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
 // PASS 3: PASS 0 for a geometry without UNIFIED surfaces (no such code in the kernel).
 template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS == 2 ? RT_UNI_WAVES : RT_PHYS_WAVES) k_level_phys(const KArgs a) {
     extern __shared__ double smem[];
-    if constexpr (PASS == 2) { if (a.defer_n[blockIdx.x] == 0) return; } // nothing put aside in this segment
+    if constexpr (PASS == 2) { if (a.defer_n[2 * blockIdx.x] + a.defer_n[2 * blockIdx.x + 1] == 0) return; } // nothing put aside in this segment
     // LDS image: surface rows (per-lane gather of the winning surface) | this step's tally row | step counters
     double* s_surf = smem;
     double* s_tab = s_surf + a.S * ROW;
@@ -476,7 +477,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
     const uint32_t child0 = PASS == 2 ? a.seg_out[blockIdx.x] : 0u;
-    if (threadIdx.x < 5) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred, dense
+    if (threadIdx.x < 6) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred (UNIFIED), dense, deferred (bulk scatters)
     __syncthreads();
     Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr, (udptr)a.prog, a.nprog };
     const Prm P = a.P;
@@ -485,22 +486,26 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     const int k = a.step;
     KArgs t = a; t.rows_lds = 1; // tally_add(): row 0 of the LDS image is step k
     const int64_t seg0 = (int64_t)blockIdx.x * a.seg_cap;
-    int64_t n = seg0 + (int64_t)(PASS == 2 ? a.defer_n[blockIdx.x] : a.seg_in[blockIdx.x]);
+    // PASS 2 walks the front of its list (padded to whole waves), then the back
+    const int64_t nf = PASS == 2 ? (int64_t)a.defer_n[2 * blockIdx.x] : 0, nb = PASS == 2 ? (int64_t)a.defer_n[2 * blockIdx.x + 1] : 0, nfp = (nf + 63) & ~(int64_t)63;
+    int64_t n = seg0 + (PASS == 2 ? nfp + nb : (int64_t)a.seg_in[blockIdx.x]);
     constexpr bool listed = PASS == 2 || PASS == 1;
     if constexpr (PASS == 1) { // sort the segment's rays into the two lists; this launch then takes the dense one
         for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
             const int64_t idx = base + lane_id();
             if (idx < n) {
                 const int so = a.hit_so[idx];
-                bool heavy = so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED;
+                bool heavy = so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED, bulk = false;
                 if (!heavy && so >= 0) { // bulk scatter before the surface: the other launch has the Rayleigh code
                     const double* row = s_surf + (so >> 2) * ROW;
                     if ((((so & 3) - 1) < 0 ? row[21] : row[20]) < INFINITY) {
                         Hit h; h.l = a.hit_l[idx]; h.surf = so >> 2; h.orient = (so & 3) - 1;
-                        heavy = level_ray_scatters(G, P, a.in_i[idx], (uint32_t)a.in_m[idx], k, h);
+                        heavy = bulk = level_ray_scatters(G, P, a.in_i[idx], (uint32_t)a.in_m[idx], k, h);
                     }
                 }
-                if (heavy) a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
+                // the list of the other launch: UNIFIED rays from the front, bulk scatters from the back, so that its waves are of one kind
+                if (heavy && bulk) a.defer[seg0 + a.seg_cap - 1 - (int64_t)wave_alloc_lds(&s_cnt[5])] = (uint32_t)(idx - seg0);
+                else if (heavy) a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
                 else a.dense[seg0 + (int64_t)wave_alloc_lds(&s_cnt[4])] = (uint32_t)(idx - seg0);
             }
         }
@@ -512,9 +517,13 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
         int64_t idx = base + lane_id();
         // PASS 2: the wave works together on the rough-surface loop (unified_wave), so all 64 lanes go through the step;
         // those behind the end of the list repeat its last ray and leave no trace
-        const bool act = idx < n;
+        bool act = idx < n;
         constexpr bool WAVE = PASS == 2 && CF == FLAG_SINGLE;
-        if constexpr (WAVE) { if (!act) idx = n - 1; }
+        if constexpr (PASS == 2) { // place in the list; lanes behind the end of either part stand on its last ray
+            const int64_t j = idx - seg0;
+            if (base - seg0 < nfp) { act = j < nf; idx = seg0 + (act ? j : nf - 1); }
+            else { const int64_t jb = j - nfp; act = jb < nb; idx = seg0 + a.seg_cap - 1 - (act ? jb : nb - 1); }
+        }
         if (act || WAVE) {
             if (listed) idx = seg0 + (int64_t)list[idx];
             const int so = a.hit_so[idx];
@@ -588,7 +597,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
         const uint32_t kept = (int64_t)s_cnt[2] < a.seg_cap ? s_cnt[2] : (uint32_t)a.seg_cap; // beyond that: overflow, the run is repeated
         a.seg_out[blockIdx.x] = kept;
         if (kept > child0) atomicAdd(a.tail, (unsigned long long)(kept - child0));
-        if constexpr (PASS == 1) a.defer_n[blockIdx.x] = s_cnt[3];
+        if constexpr (PASS == 1) { a.defer_n[2 * blockIdx.x] = s_cnt[3]; a.defer_n[2 * blockIdx.x + 1] = s_cnt[5]; }
     }
 }
 
@@ -927,7 +936,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     const int nseg_max = ctx->n_cu * ctx->seg_per_cu;
     // geometry with UNIFIED surfaces: the rays that end on them get a physics launch of their own (k_level_phys PASS 1 + 2)
     const bool defer = level && ctx->has_unified && ctx->defer_unified; // (a launch of their own for bulk scatters alone did not pay: SBC light collection 6.1e9 -> 5.6e9)
-    if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 3 * (size_t)nseg_max)); }
+    if (level) { CK(dev_alloc(ctx, b_hl, 8 * (size_t)q_cap)); CK(dev_alloc(ctx, b_hso, 4 * (size_t)q_cap)); CK(dev_alloc(ctx, b_seg, sizeof(uint32_t) * 4 * (size_t)nseg_max)); }
     if (defer) CK(dev_alloc(ctx, b_defer, 2 * 4 * (size_t)q_cap));
     DevBuf b_in, b_hs, b_hr, b_q0d, b_q0i, b_q0m, b_q1d, b_q1i, b_q1m, b_rec, b_rstep, b_rray, b_rpar, b_rflag, b_fin, b_rows;
     Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
