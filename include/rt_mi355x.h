@@ -227,6 +227,12 @@ int rt_result_num_records(rt_ctx* ctx, int64_t* n);
 /* records in device order + ordering metadata; the host wrapper sorts them into the reference's order */
 int rt_result_records(rt_ctx* ctx, double* rec /*[n][RT_REC_COLS]*/, int32_t* step /*[n]*/,
                       int64_t* ray_id /*[n]*/, int64_t* parent /*[n]*/, int32_t* flags /*[n]*/);
+/* The arrays of python/rayInterfaces.py:4-20 for one step without a copy of the whole record table: records
+ * order[0..n) (indices into the record table; NULL = the first n) split into fields, field f = record columns
+ * [col0[f], col0[f] + ncols[f]) as a dense [n][ncols[f]] array at outs[f].  Any of rec, step, ... of
+ * rt_result_records may be NULL, so the wrapper fetches the ordering metadata alone and then calls this per step. */
+int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_t n, int32_t nfields, const int32_t* col0, const int32_t* ncols,
+                            double* const* outs);
 int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);
 /* Final rows without the trip through host memory (no reference counterpart; the reference's reduction,
  * python/BubbleImageCreator.py:134-165, lives in host arrays): traces with RT_FLAG_FINAL_ROWS write row (ray id -

@@ -101,15 +101,36 @@ class Context(object):
         out = {"num_steps": ns, "table": tab}
         if want_records:
             n = C.c_int64(); self._check(self.L.rt_result_num_records(self.h, C.byref(n))); n = n.value
-            rec = np.zeros((n, _lib.REC_COLS)); step = np.zeros(n, np.int32); ray = np.zeros(n, np.int64); par = np.zeros(n, np.int64); fl = np.zeros(n, np.int32)
+            meta_only = isinstance(want_records, str) and want_records == "meta"  # the rows stay in the library: interfaces() splits them into fields
+            rec = None if meta_only else np.zeros((n, _lib.REC_COLS))
+            step = np.zeros(n, np.int32); ray = np.zeros(n, np.int64); par = np.zeros(n, np.int64); fl = np.zeros(n, np.int32)
             if n:
-                self._check(self.L.rt_result_records(self.h, _dp(rec), step.ctypes.data_as(C.POINTER(C.c_int32)), ray.ctypes.data_as(C.POINTER(C.c_int64)),
+                self._check(self.L.rt_result_records(self.h, None if meta_only else _dp(rec), step.ctypes.data_as(C.POINTER(C.c_int32)), ray.ctypes.data_as(C.POINTER(C.c_int64)),
                                                      par.ctypes.data_as(C.POINTER(C.c_int64)), fl.ctypes.data_as(C.POINTER(C.c_int32))))
             out.update(rec=rec, step=step, ray=ray, parent=par, flags=fl)
         if want_final:
             fin = np.zeros((n_rays, _lib.FINAL_COLS)); self._check(self.L.rt_result_final(self.h, _dp(fin))); out["final"] = fin
         ms = C.c_double(); nl = C.c_int32(); self._check(self.L.rt_result_timing(self.h, C.byref(ms), C.byref(nl)))
         out["kernel_ms"] = ms.value; out["n_launches"] = nl.value
+        return out
+
+    def interfaces(self, groups):
+        """one rayInterfaces (python/rayInterfaces.py:4-20) per non-empty index array of `groups` (order_records): the
+        library splits the records of the last trace into the fields, rows in the order given"""
+        nf = len(_FIELDS)
+        col0 = (C.c_int32 * nf)(*[f[1] for f in _FIELDS]); ncols = (C.c_int32 * nf)(*[f[2] for f in _FIELDS])
+        out = []
+        for g in groups:
+            if not g.size:
+                continue
+            g = np.ascontiguousarray(g, np.int64)
+            ri = rayInterfaces()
+            arrs = [np.empty((g.size, f[2]) if f[2] > 1 else (g.size,)) for f in _FIELDS]
+            ptrs = (C.POINTER(C.c_double) * nf)(*[_dp(a) for a in arrs])
+            self._check(self.L.rt_result_record_fields(self.h, g.ctypes.data_as(C.POINTER(C.c_int64)), g.size, nf, col0, ncols, ptrs))
+            for f, a in zip(_FIELDS, arrs):
+                setattr(ri, f[0], a)
+            out.append(ri)
         return out
 
     def final_rows_device(self, n_rays):
@@ -172,13 +193,13 @@ def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.flo
     finally:
         if device_rows:
             c.final_rows_host()
-    res = c.results(bool(full_output), not device_rows, n)
+    res = c.results("meta" if full_output else False, not device_rows, n)
     if device_rows:
         res["final"] = rows
     ris = []
     if full_output:
         groups = order_records(res["step"], res["ray"], res["parent"], res["flags"], res["num_steps"])
-        ris = [_interface_from(res["rec"][g]) for g in groups if g.size]
+        ris = c.interfaces(groups)
     return res["table"], res["final"], ris
 
 
@@ -248,6 +269,13 @@ def order_records(step, ray, parent, flags, num_steps):
         pos[idx] = np.arange(idx.size)
         out.append(idx)
     return out
+
+
+# fields of python/rayInterfaces.py:4-20 as (name, first record column, columns): the layout of RT_REC_COLS in include/rt_mi355x.h
+_FIELDS = (("incoming_ray", 0, 10), ("refracted_ray", 10, 10), ("reflected_ray", 20, 10), ("intersection_point", 30, 3), ("surface_normal", 33, 3),
+           ("ray_index", 36, 1), ("surface_index", 37, 1), ("distance_traveled", 38, 1), ("n_incident", 39, 1), ("n_transmitted", 40, 1),
+           ("bulkabs_incident", 41, 1), ("bulkabs_transmitted", 42, 1), ("rayleigh_incident", 43, 1), ("rayleigh_transmitted", 44, 1),
+           ("orientation", 45, 1), ("surface_number", 46, 1), ("is_rayleigh", 47, 1))
 
 
 def _interface_from(rec):
@@ -336,7 +364,7 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
             c.L.rt_set_record_sink(c.h, C.cast(None, _lib.RECORD_SINK), None)
         if dev_rows is not None:
             c.final_rows_host()
-    res = c.results(want_rec, bool(return_final) and dev_rows is None, n)
+    res = c.results("meta" if want_rec else False, bool(return_final) and dev_rows is None, n)
     if dev_rows is not None:
         res["final"] = dev_rows
     ns = res["num_steps"]
@@ -346,20 +374,18 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     raytable = []
     if want_rec:
         groups = order_records(res["step"], res["ray"], res["parent"], res["flags"], ns)
-        ris = [_interface_from(res["rec"][g]) for g in groups if g.size]
+        ris = c.interfaces(groups)
         if output_raytable:  # MATLAB/RayTracer2.m:249-253, 543-548 (numpy port broken)
             raytable = np.zeros((K + 1, n, 13))
             raytable[0, :, 0:3] = sp; raytable[0, :, 3:13] = ry
             raytable[0, :, 3:6] /= np.linalg.norm(raytable[0, :, 3:6], axis=1, keepdims=True)
             raytable[0, :, 6:9] /= np.linalg.norm(raytable[0, :, 6:9], axis=1, keepdims=True)
-            for g in groups:
-                if not g.size:
-                    continue
+            for g, ri in zip([g for g in groups if g.size], ris):
                 k = int(res["step"][g[0]])
                 cut = (res["flags"][g] & 1) == 0  # never reflected <=> positive ray_index
                 ix = res["ray"][g][cut] - ray_id_base
-                raytable[k + 1, ix, 0:3] = res["rec"][g][cut, 30:33]
-                raytable[k + 1, ix, 3:13] = res["rec"][g][cut, 10:20]
+                raytable[k + 1, ix, 0:3] = ri.intersection_point[cut]
+                raytable[k + 1, ix, 3:13] = ri.refracted_ray[cut]
         if full_output:
             ray_interfaces = ris
     out = [np.array(ray_interfaces, dtype=object), res["table"], raytable]
