@@ -175,7 +175,8 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
  * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "match_max_level" (rt_match_endpoints: deepest level of
  * the search tree, default 10), "stream_overlap" (0: record streaming copies and calls the sink between the kernels of
  * two chunks, as up to r1k), "stream_stage_gb" (bytes of records per chunk handed to a record sink, default 2; two
- * pinned host buffers of that size are kept), "release_workspace" (free the pooled device buffers and those two). */
+ * pinned host buffers of that size are kept), "accumulate_stage_gb" (the same for records that accumulate for
+ * rt_result_records in single-child runs, default 0.25), "release_workspace" (free the pooled device buffers and those two). */
 int rt_set_option(rt_ctx* ctx, const char* key, double value);
 
 /* Record streaming (no reference counterpart: the reference keeps every rayInterfaces array in

@@ -646,6 +646,26 @@ __global__ void k_gen_camera(const double* cam, int64_t first, int64_t n, double
 } // namespace
 
 // ================================================================================================ host side
+// host array that grows without being filled (std::vector::resize would write 384 B per record just to have them overwritten)
+struct RawBuf {
+    double* p = nullptr; size_t n = 0, cap = 0;
+    ~RawBuf() { free(p); }
+    bool resize(size_t m) {
+        if (m > cap) { size_t nc = std::max(m, cap + cap / 2); double* q = (double*)realloc(p, nc * sizeof(double)); if (!q) return false; p = q; cap = nc; }
+        n = m; return true;
+    }
+    void clear() { n = 0; }
+    double* data() { return p; }
+    size_t size() const { return n; }
+};
+static void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const int nt = (int)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), bytes >> 24);
+    if (nt <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th; const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+    for (int t = 0; t < nt; t++) { const size_t o = std::min(bytes, (size_t)t * per), e = std::min(bytes, o + per); if (e > o) th.emplace_back([=] { memcpy((char*)dst + o, (const char*)src + o, e - o); }); }
+    for (auto& t : th) t.join();
+}
+
 struct rt_ctx {
     int device = 0; hipStream_t stream = nullptr; int n_cu = 0; size_t hbm = 0; std::string name;
     std::string err;
@@ -662,7 +682,7 @@ struct rt_ctx {
     // results of the last trace
     int K = 0; int num_steps = 0; int64_t n_rays = 0;
     std::vector<double> table; std::vector<int64_t> n_live, n_scat;
-    std::vector<double> rec; std::vector<int32_t> rec_step, rec_flags; std::vector<int64_t> rec_ray, rec_parent;
+    RawBuf rec; std::vector<int32_t> rec_step, rec_flags; std::vector<int64_t> rec_ray, rec_parent;
     std::vector<double> fin;
     double* d_fin_user = nullptr; int64_t fin_user_rows = 0; // rt_set_final_rows_device: final rows stay in the caller's device buffer
     std::vector<std::pair<void*, size_t>> pool; // cached device buffers (see DevBuf)
@@ -670,7 +690,7 @@ struct rt_ctx {
     // record streaming: two pinned host stages, a copy stream; the D2H copy of chunk c runs under the sink call of chunk c-1 and the kernels of chunk c+1
     hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2] = { nullptr, nullptr }, ev_copied[2] = { nullptr, nullptr };
     char* pin[2] = { nullptr, nullptr }; size_t pin_bytes[2] = { 0, 0 };
-    bool stream_overlap = true; size_t stream_stage_bytes = (size_t)2 << 30;
+    bool stream_overlap = true; size_t stream_stage_bytes = (size_t)2 << 30, accumulate_stage_bytes = (size_t)256 << 20;
     double kernel_ms = 0; int n_launches = 0;
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
@@ -744,6 +764,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
         for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); ctx->pin[s] = nullptr; ctx->pin_bytes[s] = 0; }
     }
     else if (k == "stream_overlap") ctx->stream_overlap = value != 0;
+    else if (k == "accumulate_stage_gb") { if (!(value > 0)) { ctx->err = "rt_set_option: accumulate_stage_gb must be positive"; return -1; } ctx->accumulate_stage_bytes = (size_t)(value * (double)(1ull << 30)); }
     else if (k == "stream_stage_gb") { if (!(value > 0)) { ctx->err = "rt_set_option: stream_stage_gb must be positive"; return -1; } ctx->stream_stage_bytes = (size_t)(value * (double)(1ull << 30)); }
     else if (k == "frames") ctx->use_frames = value != 0;
     else if (k == "level_steps") ctx->level_steps = (int)value;
@@ -909,8 +930,10 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     const size_t rec_bytes = (size_t)REC * 8 + 4 + 8 + 8 + 4;
     int64_t chunk = n, rec_cap = 0, q_cap = 0;
     // records that stream to a sink: the chunk's records + two packed copies of them (one in flight to the host, one being filled), each at most one stage
-    const bool piped = full && ctx->sink && ctx->stream_overlap;
-    const size_t Wrec = piped ? std::min(W / 3, ctx->stream_stage_bytes) : W;
+    // Records that accumulate for rt_result_records take the same way in single-child runs (smaller stages: pinning memory
+    // costs ~0.25 s per GiB once per context); ray-splitting runs cannot bound the records of a pass and keep one buffer.
+    const bool piped = full && ctx->stream_overlap && (ctx->sink || single);
+    const size_t Wrec = piped ? std::min(W / 3, ctx->sink ? ctx->stream_stage_bytes : ctx->accumulate_stage_bytes) : W;
     if (single) {
         if (full) { chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(Wrec / (rec_bytes * (size_t)K)))); rec_cap = chunk * K; }
         if (mode == 0 && !d_soa) chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)(W / (13 * 8 * 2))));
@@ -970,7 +993,17 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (hipEventSynchronize(ctx->ev_copied[s]) != hipSuccess) { ctx->err = "rt_trace: record copy failed"; return -1; }
         const int64_t nr = stg[s].nrec; char* h = ctx->pin[s];
         int64_t* h_ray = (int64_t*)(h + (size_t)nr * REC * 8); int64_t* h_par = h_ray + nr; int32_t* h_step = (int32_t*)(h_par + nr); int32_t* h_fl = h_step + nr;
-        if (ctx->sink(ctx->sink_user, nr, (const double*)h, h_step, h_ray, h_par, h_fl, stg[s].first, stg[s].m) != 0) { ctx->err = "rt_trace: the record sink asked to stop"; return -4; }
+        if (ctx->sink) {
+            if (ctx->sink(ctx->sink_user, nr, (const double*)h, h_step, h_ray, h_par, h_fl, stg[s].first, stg[s].m) != 0) { ctx->err = "rt_trace: the record sink asked to stop"; return -4; }
+            return 0;
+        }
+        const size_t base = ctx->rec_step.size();
+        if (!ctx->rec.resize((base + (size_t)nr) * REC)) { ctx->err = "rt_trace: out of host memory for the records"; return -1; }
+        parallel_copy(ctx->rec.data() + base * REC, h, (size_t)nr * REC * 8);
+        ctx->rec_step.insert(ctx->rec_step.end(), h_step, h_step + nr); ctx->rec_flags.insert(ctx->rec_flags.end(), h_fl, h_fl + nr);
+        ctx->rec_ray.insert(ctx->rec_ray.end(), h_ray, h_ray + nr);
+        ctx->rec_parent.resize(base + (size_t)nr);
+        for (int64_t i = 0; i < nr; i++) ctx->rec_parent[base + (size_t)i] = h_par[i] >= 0 ? h_par[i] + (int64_t)base : h_par[i]; // parents are chunk-local
         return 0;
     };
 
@@ -1133,7 +1166,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 size_t base = ctx->rec_step.size();
                 DevBuf rows; CK(dev_alloc(ctx, rows, (size_t)REC * 8 * nrec));
                 hipLaunchKernelGGL(k_rec_to_rows, dim3((unsigned)((nrec * REC + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_rec.p, rec_cap, (int64_t)nrec, (double*)rows.p);
-                ctx->rec.resize((base + nrec) * REC); ctx->rec_step.resize(base + nrec); ctx->rec_flags.resize(base + nrec); ctx->rec_ray.resize(base + nrec); ctx->rec_parent.resize(base + nrec);
+                if (!ctx->rec.resize((base + nrec) * REC)) { ctx->err = "rt_trace: out of host memory for the records"; rc = -1; break; }
+                ctx->rec_step.resize(base + nrec); ctx->rec_flags.resize(base + nrec); ctx->rec_ray.resize(base + nrec); ctx->rec_parent.resize(base + nrec);
                 CK(hipMemcpyAsync(ctx->rec.data() + base * REC, rows.p, (size_t)REC * 8 * nrec, hipMemcpyDeviceToHost, ctx->stream));
                 CK(hipMemcpyAsync(ctx->rec_step.data() + base, b_rstep.p, 4 * nrec, hipMemcpyDeviceToHost, ctx->stream));
                 CK(hipMemcpyAsync(ctx->rec_flags.data() + base, b_rflag.p, 4 * nrec, hipMemcpyDeviceToHost, ctx->stream));
