@@ -234,6 +234,10 @@ int rt_result_records(rt_ctx* ctx, double* rec /*[n][RT_REC_COLS]*/, int32_t* st
  * rt_result_records may be NULL, so the wrapper fetches the ordering metadata alone and then calls this per step. */
 int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_t n, int32_t nfields, const int32_t* col0, const int32_t* ncols,
                             double* const* outs);
+/* The same for any table of record rows, e.g. the one a record sink is handed (no context: plain host work).
+ * Returns 0, -1 (bad column range) or -2 (record index out of range). */
+int rt_split_record_fields(const double* rows /*[n_rows][RT_REC_COLS]*/, int64_t n_rows, const int64_t* order, int64_t n, int32_t nfields,
+                           const int32_t* col0, const int32_t* ncols, double* const* outs);
 int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);
 /* Final rows without the trip through host memory (no reference counterpart; the reference's reduction,
  * python/BubbleImageCreator.py:134-165, lives in host arrays): traces with RT_FLAG_FINAL_ROWS write row (ray id -

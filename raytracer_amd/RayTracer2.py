@@ -114,9 +114,10 @@ class Context(object):
         out["kernel_ms"] = ms.value; out["n_launches"] = nl.value
         return out
 
-    def interfaces(self, groups):
+    def interfaces(self, groups, rows=None, n_rows=0):
         """one rayInterfaces (python/rayInterfaces.py:4-20) per non-empty index array of `groups` (order_records): the
-        library splits the records of the last trace into the fields, rows in the order given"""
+        library splits the records of the last trace - or the row table `rows` (a ctypes double pointer, n_rows rows) a
+        record sink was handed - into the fields, rows in the order given"""
         nf = len(_FIELDS)
         col0 = (C.c_int32 * nf)(*[f[1] for f in _FIELDS]); ncols = (C.c_int32 * nf)(*[f[2] for f in _FIELDS])
         out = []
@@ -127,7 +128,11 @@ class Context(object):
             ri = rayInterfaces()
             arrs = [np.empty((g.size, f[2]) if f[2] > 1 else (g.size,)) for f in _FIELDS]
             ptrs = (C.POINTER(C.c_double) * nf)(*[_dp(a) for a in arrs])
-            self._check(self.L.rt_result_record_fields(self.h, g.ctypes.data_as(C.POINTER(C.c_int64)), g.size, nf, col0, ncols, ptrs))
+            gp = g.ctypes.data_as(C.POINTER(C.c_int64))
+            if rows is None:
+                self._check(self.L.rt_result_record_fields(self.h, gp, g.size, nf, col0, ncols, ptrs))
+            elif self.L.rt_split_record_fields(rows, int(n_rows), gp, g.size, nf, col0, ncols, ptrs) != 0:
+                raise _lib.RayTracerLibraryError("rt_split_record_fields: bad request")
             for f, a in zip(_FIELDS, arrs):
                 setattr(ri, f[0], a)
             out.append(ri)
@@ -230,10 +235,10 @@ def _install_sink(c, record_sink, K):
     def cb(user, n, rec, step, ray, parent, flags, first, nrays):
         try:
             n = int(n)
-            r = np.ctypeslib.as_array(rec, shape=(n, _lib.REC_COLS)); st = np.ctypeslib.as_array(step, shape=(n,))
+            st = np.ctypeslib.as_array(step, shape=(n,))
             ry = np.ctypeslib.as_array(ray, shape=(n,)); pa = np.ctypeslib.as_array(parent, shape=(n,)); fl = np.ctypeslib.as_array(flags, shape=(n,))
             groups = order_records(st, ry, pa, fl, K)
-            record_sink(state["chunk"], int(first), int(nrays), [_interface_from(r[g]) for g in groups if g.size])
+            record_sink(state["chunk"], int(first), int(nrays), c.interfaces(groups, rec, n))
             state["chunk"] += 1
             return 0
         except Exception as e:  # never let an exception cross the C boundary
@@ -276,18 +281,6 @@ _FIELDS = (("incoming_ray", 0, 10), ("refracted_ray", 10, 10), ("reflected_ray",
            ("ray_index", 36, 1), ("surface_index", 37, 1), ("distance_traveled", 38, 1), ("n_incident", 39, 1), ("n_transmitted", 40, 1),
            ("bulkabs_incident", 41, 1), ("bulkabs_transmitted", 42, 1), ("rayleigh_incident", 43, 1), ("rayleigh_transmitted", 44, 1),
            ("orientation", 45, 1), ("surface_number", 46, 1), ("is_rayleigh", 47, 1))
-
-
-def _interface_from(rec):
-    ri = rayInterfaces()
-    ri.incoming_ray = rec[:, 0:10].copy(); ri.refracted_ray = rec[:, 10:20].copy(); ri.reflected_ray = rec[:, 20:30].copy()
-    ri.intersection_point = rec[:, 30:33].copy(); ri.surface_normal = rec[:, 33:36].copy()
-    ri.ray_index = rec[:, 36].copy(); ri.surface_index = rec[:, 37].copy(); ri.distance_traveled = rec[:, 38].copy()
-    ri.n_incident = rec[:, 39].copy(); ri.n_transmitted = rec[:, 40].copy()
-    ri.bulkabs_incident = rec[:, 41].copy(); ri.bulkabs_transmitted = rec[:, 42].copy()
-    ri.rayleigh_incident = rec[:, 43].copy(); ri.rayleigh_transmitted = rec[:, 44].copy()
-    ri.orientation = rec[:, 45].copy(); ri.surface_number = rec[:, 46].copy(); ri.is_rayleigh = rec[:, 47].copy()
-    return ri
 
 
 def parse_args(rays, max_scat, min_travel_len, follow_thresh, tir_handling, compat):

@@ -1285,18 +1285,18 @@ extern "C" int rt_result_table(rt_ctx* ctx, double* table) { memcpy(table, ctx->
 extern "C" int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live, int64_t* n_scat) {
     memcpy(n_live, ctx->n_live.data(), 8 * (size_t)ctx->K); memcpy(n_scat, ctx->n_scat.data(), 8 * (size_t)ctx->K); return 0;
 }
-// Records order[0..n) of the last trace split into fields: field f = columns [col0[f], col0[f] + ncols[f]) as a dense
-// [n][ncols[f]] array at outs[f].  One pass over the rows, on several host threads for large n.
-extern "C" int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_t n, int32_t nfields, const int32_t* col0, const int32_t* ncols, double* const* outs) {
-    const int64_t have = (int64_t)ctx->rec_step.size();
-    for (int f = 0; f < nfields; f++) if (col0[f] < 0 || ncols[f] < 1 || col0[f] + ncols[f] > REC) { ctx->err = "rt_result_record_fields: bad column range"; return -1; }
+// Records order[0..n) of a row table split into fields: field f = columns [col0[f], col0[f] + ncols[f]) as a dense
+// [n][ncols[f]] array at outs[f].  One pass over the rows, on several host threads for large n.  Returns 0, -1 (bad
+// column range) or -2 (record index out of range).
+extern "C" int rt_split_record_fields(const double* rows, int64_t n_rows, const int64_t* order, int64_t n, int32_t nfields, const int32_t* col0, const int32_t* ncols,
+                                      double* const* outs) {
+    for (int f = 0; f < nfields; f++) if (col0[f] < 0 || ncols[f] < 1 || col0[f] + ncols[f] > REC) return -1;
     std::atomic<int> bad{ 0 };
-    const double* rec = ctx->rec.data();
     auto work = [&](int64_t j0, int64_t j1) {
         for (int64_t j = j0; j < j1; j++) {
             const int64_t i = order ? order[j] : j;
-            if (i < 0 || i >= have) { bad = 1; continue; }
-            const double* row = rec + (size_t)i * REC;
+            if (i < 0 || i >= n_rows) { bad = 1; continue; }
+            const double* row = rows + (size_t)i * REC;
             for (int f = 0; f < nfields; f++) { double* o = outs[f] + (size_t)j * ncols[f]; const double* r = row + col0[f]; for (int c = 0; c < ncols[f]; c++) o[c] = r[c]; }
         }
     };
@@ -1307,8 +1307,13 @@ extern "C" int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_
         for (int t = 0; t < nt; t++) th.emplace_back(work, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
         for (auto& t : th) t.join();
     }
-    if (bad) { ctx->err = "rt_result_record_fields: record index out of range"; return -1; }
-    return 0;
+    return bad ? -2 : 0;
+}
+extern "C" int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_t n, int32_t nfields, const int32_t* col0, const int32_t* ncols, double* const* outs) {
+    const int rc = rt_split_record_fields(ctx->rec.data(), (int64_t)ctx->rec_step.size(), order, n, nfields, col0, ncols, outs);
+    if (rc == -1) ctx->err = "rt_result_record_fields: bad column range";
+    if (rc == -2) ctx->err = "rt_result_record_fields: record index out of range";
+    return rc ? -1 : 0;
 }
 extern "C" int rt_result_num_records(rt_ctx* ctx, int64_t* n) { *n = (int64_t)ctx->rec_step.size(); return 0; }
 extern "C" int rt_result_records(rt_ctx* ctx, double* rec, int32_t* step, int64_t* ray_id, int64_t* parent, int32_t* flags) {
