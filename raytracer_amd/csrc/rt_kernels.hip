@@ -402,6 +402,9 @@ template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_b
 #ifndef RT_PHYS_WAVES
 #define RT_PHYS_WAVES 3
 #endif
+#ifndef RT_P1_WAVES
+#define RT_P1_WAVES RT_PHYS_WAVES /* the common launch of a step with two (k_level_phys PASS 1) */
+#endif
 #ifndef RT_UNI_WAVES
 #define RT_UNI_WAVES 2 /* the pass that runs the UNIFIED rough-surface loop in line */
 #endif
@@ -468,7 +471,7 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
 // PASS 2: the listed rays, children appended behind those of pass 1; for CF == FLAG_SINGLE (tallies only) the wave
 // works through the UNIFIED model together (unified_wave), otherwise every lane runs it in line.
 // PASS 3: PASS 0 for a geometry without UNIFIED surfaces (no such code in the kernel).
-template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS == 2 ? RT_UNI_WAVES : RT_PHYS_WAVES) k_level_phys(const KArgs a) {
+template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS == 2 ? RT_UNI_WAVES : (PASS == 1 ? RT_P1_WAVES : RT_PHYS_WAVES)) k_level_phys(const KArgs a) {
     extern __shared__ double smem[];
     if constexpr (PASS == 2) { if (a.defer_n[2 * blockIdx.x] + a.defer_n[2 * blockIdx.x + 1] == 0) return; } // nothing put aside in this segment
     // LDS image: surface rows (per-lane gather of the winning surface) | this step's tally row | step counters

@@ -11,5 +11,5 @@ if [ -n "$rev" ] && [ "$rev" != "WT" ]; then
   git -C $root show $rev:include/rt_mi355x.h > $tmp/include/rt_mi355x.h
   src=$tmp/raytracer_amd/csrc
 fi
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -munsafe-fp-atomics -I$root/include "$@" -o $root/build/rt_$name.so $src/rt_kernels.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -munsafe-fp-atomics -pthread -I$root/include "$@" -o $root/build/rt_$name.so $src/rt_kernels.hip
 echo built build/rt_$name.so
