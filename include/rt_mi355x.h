@@ -175,7 +175,9 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
  * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "match_max_level" (rt_match_endpoints: deepest level of
  * the search tree, default 10), "stream_overlap" (0: record streaming copies and calls the sink between the kernels of
  * two chunks, as up to r1k), "stream_stage_gb" (bytes of records per chunk handed to a record sink, default 2; two
- * pinned host buffers of that size are kept), "accumulate_stage_gb" (the same for records that accumulate for
+ * pinned host buffers of that size are kept), "upload_chunk" (rays per piece in which host inputs
+ * are staged through two pinned buffers, default 2^21; 0: one hipMemcpy from the caller's pageable arrays),
+ * "accumulate_stage_gb" (the same for records that accumulate for
  * rt_result_records in single-child runs, default 0.25), "release_workspace" (free the pooled device buffers and those two). */
 int rt_set_option(rt_ctx* ctx, const char* key, double value);
 

@@ -693,6 +693,10 @@ struct rt_ctx {
     // record streaming: two pinned host stages, a copy stream; the D2H copy of chunk c runs under the sink call of chunk c-1 and the kernels of chunk c+1
     hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2] = { nullptr, nullptr }, ev_copied[2] = { nullptr, nullptr };
     char* pin[2] = { nullptr, nullptr }; size_t pin_bytes[2] = { 0, 0 };
+    // host inputs of large runs: pieces of upload_chunk rays are staged in two pinned buffers by host threads, one being filled
+    // while the other is copied to the device
+    char* in_pin[2] = { nullptr, nullptr }; size_t in_pin_bytes[2] = { 0, 0 }; hipEvent_t ev_up[2] = { nullptr, nullptr };
+    int64_t upload_chunk = (int64_t)1 << 21;
     bool stream_overlap = true; size_t stream_stage_bytes = (size_t)2 << 30, accumulate_stage_bytes = (size_t)256 << 20;
     double kernel_ms = 0; int n_launches = 0;
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
@@ -742,6 +746,7 @@ extern "C" void rt_free(rt_ctx* ctx) {
     hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog); hipFree(ctx->d_cam); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps); hipFree(ctx->d_lvl);
     for (auto& pb : ctx->pool) hipFree(pb.first);
     for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); if (ctx->ev_ready[s]) hipEventDestroy(ctx->ev_ready[s]); if (ctx->ev_copied[s]) hipEventDestroy(ctx->ev_copied[s]); }
+    for (int s = 0; s < 2; s++) { if (ctx->in_pin[s]) hipHostFree(ctx->in_pin[s]); if (ctx->ev_up[s]) hipEventDestroy(ctx->ev_up[s]); }
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -765,7 +770,9 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "release_workspace") {
         hipSetDevice(ctx->device); for (auto& pb : ctx->pool) hipFree(pb.first); ctx->pool.clear();
         for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); ctx->pin[s] = nullptr; ctx->pin_bytes[s] = 0; }
+        for (int s = 0; s < 2; s++) { if (ctx->in_pin[s]) hipHostFree(ctx->in_pin[s]); ctx->in_pin[s] = nullptr; ctx->in_pin_bytes[s] = 0; }
     }
+    else if (k == "upload_chunk") ctx->upload_chunk = (int64_t)value; // rays per piece; 0: one hipMemcpy from pageable memory
     else if (k == "stream_overlap") ctx->stream_overlap = value != 0;
     else if (k == "accumulate_stage_gb") { if (!(value > 0)) { ctx->err = "rt_set_option: accumulate_stage_gb must be positive"; return -1; } ctx->accumulate_stage_bytes = (size_t)(value * (double)(1ull << 30)); }
     else if (k == "stream_stage_gb") { if (!(value > 0)) { ctx->err = "rt_set_option: stream_stage_gb must be positive"; return -1; } ctx->stream_stage_bytes = (size_t)(value * (double)(1ull << 30)); }
@@ -958,6 +965,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         q_cap += (int64_t)ctx->n_cu * ctx->seg_per_cu; // segments of the level path round the capacity up
         if (full) rec_cap = std::max<int64_t>((int64_t)(Wrec / rec_bytes), 1 << 16), rec_cap = std::min<int64_t>(rec_cap, (int64_t)1 << 31);
     }
+    // host inputs of more than two upload pieces come in through two pinned stages (see the chunk loop)
+    const bool piped_in = mode == 0 && !d_soa && ctx->stream_overlap && ctx->upload_chunk > 0 && std::min(n, chunk) > 2 * ctx->upload_chunk;
     if (full && rec_cap < chunk) { rec_cap = chunk; }
 
     DevBuf b_hl, b_hso, b_seg, b_defer;
@@ -970,6 +979,14 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     Queue q[2] = { { nullptr, nullptr, nullptr, 0 }, { nullptr, nullptr, nullptr, 0 } };
     if (q_cap > 0) { if (alloc_queue(ctx, q[0], b_q0d, b_q0i, b_q0m, q_cap)) return -1; if (alloc_queue(ctx, q[1], b_q1d, b_q1i, b_q1m, q_cap)) return -1; }
     if (mode == 0 && !d_soa) { CK(dev_alloc(ctx, b_in, 13 * 8 * (size_t)chunk)); CK(dev_alloc(ctx, b_hs, 3 * 8 * (size_t)chunk)); CK(dev_alloc(ctx, b_hr, 10 * 8 * (size_t)chunk)); }
+    if (piped_in) for (int s = 0; s < 2; s++) {
+        if (!ctx->ev_up[s]) CK(hipEventCreateWithFlags(&ctx->ev_up[s], hipEventDisableTiming));
+        const size_t need = 13 * 8 * (size_t)ctx->upload_chunk;
+        if (ctx->in_pin_bytes[s] < need) {
+            if (ctx->in_pin[s]) { CK(hipHostFree(ctx->in_pin[s])); ctx->in_pin[s] = nullptr; ctx->in_pin_bytes[s] = 0; }
+            CK(hipHostMalloc((void**)&ctx->in_pin[s], need, hipHostMallocDefault)); ctx->in_pin_bytes[s] = need;
+        }
+    }
     if (full) {
         CK(dev_alloc(ctx, b_rec, (size_t)REC * 8 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rstep, 4 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rray, 8 * (size_t)rec_cap));
         CK(dev_alloc(ctx, b_rpar, 8 * (size_t)rec_cap)); CK(dev_alloc(ctx, b_rflag, 4 * (size_t)rec_cap));
@@ -1056,7 +1073,22 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         if (fin_dev) a.fin = ctx->d_fin_user + (size_t)off * FIN;
         if (mode == 0) {
             if (d_soa) { a.in_d = d_soa + off; a.in_stride = n; }
-            else {
+            else if (piped_in) {
+                // the caller's pageable arrays go through two pinned stages, upload_chunk rays at a time: host threads fill one
+                // stage while the other is on its way to the device (a plain hipMemcpy of pageable memory stages on one thread)
+                int64_t piece = 0;
+                for (int64_t o = 0; o < m && rc == 0; o += ctx->upload_chunk, piece++) {
+                    const int s = (int)(piece & 1); const int64_t mm = std::min<int64_t>(ctx->upload_chunk, m - o);
+                    if (piece >= 2) CK(hipEventSynchronize(ctx->ev_up[s]));
+                    char* pin = ctx->in_pin[s];
+                    parallel_copy(pin, h_start + (off + o) * 3, 24 * (size_t)mm); parallel_copy(pin + 24 * (size_t)mm, h_rays + (off + o) * 10, 80 * (size_t)mm);
+                    CK(hipMemcpyAsync((char*)b_hs.p + 24 * (size_t)o, pin, 24 * (size_t)mm, hipMemcpyHostToDevice, ctx->stream));
+                    CK(hipMemcpyAsync((char*)b_hr.p + 80 * (size_t)o, pin + 24 * (size_t)mm, 80 * (size_t)mm, hipMemcpyHostToDevice, ctx->stream));
+                    CK(hipEventRecord(ctx->ev_up[s], ctx->stream));
+                }
+                hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_hs.p, (const double*)b_hr.p, m, (double*)b_in.p);
+                a.in_d = (const double*)b_in.p; a.in_stride = m;
+            } else {
                 CK(hipMemcpyAsync(b_hs.p, h_start + off * 3, 3 * 8 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
                 CK(hipMemcpyAsync(b_hr.p, h_rays + off * 10, 10 * 8 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
                 hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_hs.p, (const double*)b_hr.p, m, (double*)b_in.p);

@@ -70,6 +70,29 @@ def test_chunked_equals_unchunked():
     compare_results(types.SimpleNamespace(ray_interfaces=list(a[0]), absorption_table=a[1]), types.SimpleNamespace(ray_interfaces=list(b[0]), absorption_table=b[1]), tol=1e-12)
 
 
+@pytest.mark.parametrize("full_output", [True, False])
+def test_upload_pipeline_equals_one_copy(full_output):
+    """host inputs of a large run go through two pinned stages, "upload_chunk" rays at a time, one being filled by host
+    threads while the other is copied (made small here so that 40 000 rays are 14 pieces): same records, final rows and
+    tallies as the run that hands the pageable arrays to one hipMemcpy, with records and in the tally-only lean step"""
+    from raytracer_amd.RayTracer2 import Context, RayTracer2
+    sp, rays = cases.isotropic_rays(40000, 8, origin=(3, 0, 0))
+    args = (10, 1e-9, 1e-6, -1, full_output, True, False)
+    out = []
+    for chunk in (0, 3000):
+        c = Context(0)
+        try:
+            c.set_option("upload_chunk", chunk); c.set_option("level_min_rays", 0)
+            out.append(RayTracer2(sp, rays.copy(), cases.sphere_plane(), *args, seed=3, ctx=c, return_final=True))
+        finally:
+            c.close()
+    a, b = out
+    assert np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9) and a[1].any()
+    assert np.array_equal(a[3], b[3], equal_nan=True)  # final rows: one per ray, in ray order
+    if full_output:
+        compare_results(types.SimpleNamespace(ray_interfaces=list(a[0]), absorption_table=a[1]), types.SimpleNamespace(ray_interfaces=list(b[0]), absorption_table=b[1]), tol=1e-12)
+
+
 def test_nodice_small_queue_retries():
     from raytracer_amd.RayTracer2 import Context, RayTracer2
     sp, rays = cases.isotropic_rays(100000, 0, origin=(3, 0, 0))
