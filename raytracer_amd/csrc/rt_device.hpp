@@ -1326,7 +1326,7 @@ __device__ __forceinline__ V3 facet_normal_wave(bool need, Rng& g, V3 indir, V3 
         // speculatively for the rays that have no such try yet.  Stage 2, once for all of them: azimuth, the normal
         // itself and the facing test, each ray for its own first try that passed stage 1.
         unsigned long long pending = want;
-        double t_st = 0, t_ct = 1, t_u4 = 0; bool t_last = false;
+        double t_u1 = 0, t_u2 = 0, t_u3 = 0; bool t_last = false;
         while (pending) {
             const int np = __popcll(pending);
             const int c = 64 / np;                                          // tries per ray this round
@@ -1338,45 +1338,52 @@ __device__ __forceinline__ V3 facet_normal_wave(bool need, Rng& g, V3 indir, V3 
             const bool work = s < np;
             const int src = __shfl(r2l, work ? s : 0);
             // the ray whose try this lane evaluates
-            const double rs = shfl_d(sig, src), fmx = shfl_d(fmx_own, src);
+            const float rs = (float)shfl_d(sig, src); const double fmx = shfl_d(fmx_own, src);
             const uint32_t r0 = (uint32_t)__shfl((int)g.c0, src), r1 = (uint32_t)__shfl((int)g.c1, src), r2 = (uint32_t)__shfl((int)g.c2, src), rstep = (uint32_t)__shfl((int)g.step, src);
             const uint32_t ridx = (uint32_t)__shfl((int)idx0, src);
             const int rit = __shfl(it, src);
             const int tr = rit + j;                                        // number of the try
             const uint32_t b = ridx + 4u * (uint32_t)tr;
-            // uniforms b .. b+3 of that ray's stream: two Philox blocks, a third if the stream stands at an odd uniform
-            uint32_t p0, p1, p2, p3, q0, q1, q2, q3, w0 = 0, w1 = 0, w2, w3;
+            // uniforms b .. b+2 of that ray's stream: two Philox blocks (the fourth, the azimuth, is drawn below for the one try that needs it)
+            uint32_t p0, p1, p2, p3, q0, q1, q2, q3;
             const uint32_t blk = b >> 1, odd = b & 1u;
             philox(r0, r1, r2, (rstep << 20) | (blk & 0xFFFFFu), g.k0, g.k1, p0, p1, p2, p3);
             philox(r0, r1, r2, (rstep << 20) | ((blk + 1u) & 0xFFFFFu), g.k0, g.k1, q0, q1, q2, q3);
-            if (__ballot(odd != 0)) philox(r0, r1, r2, (rstep << 20) | ((blk + 2u) & 0xFFFFFu), g.k0, g.k1, w0, w1, w2, w3);
             auto u53 = [](uint32_t a, uint32_t c_) { return ((double)(a >> 5) * 67108864.0 + (double)(c_ >> 6)) * (1.0 / 9007199254740992.0); };
             const double u1 = odd ? u53(p2, p3) : u53(p0, p1), u2 = odd ? u53(q0, q1) : u53(p2, p3);
-            const double u3 = odd ? u53(q2, q3) : u53(q0, q1), u4 = odd ? u53(w0, w1) : u53(q2, q3);
-            const double th = fabs(rs * (sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2)));
-            double st, ct; sincos(th, &st, &ct);
-            const bool out_of_range = th >= 0.5 * 3.14159265358979323846;
-            const bool fail_jac = u3 * fmx > st;
+            const double u3 = odd ? u53(q2, q3) : u53(q0, q1);
+            // Single-precision screening: the polar angle to within dl (hardware log2 / cos / sin, errors of 1e-6 against a
+            // margin of 4e-3 sigma), and a try is dropped here only if it fails the range test or the Jacobian test for every
+            // angle in that interval; whatever survives is decided in double precision below, exactly as the loop does.
+            const float z32 = __builtin_sqrtf(-2.0f * 0.69314718f * __builtin_amdgcn_logf((float)(1.0 - u1))) * __builtin_amdgcn_cosf((float)u2);
+            const float th32 = __builtin_fabsf(rs * z32), dl = 4e-3f * __builtin_fabsf(rs) + 1e-6f, hi = th32 + dl;
+            const bool drop_range = th32 - dl > 1.5708f;
+            const bool drop_jac = hi < 1.57f && u3 * fmx > (double)(__builtin_amdgcn_sinf(hi * 0.15915494f) * 1.001f + 4e-6f);
             const bool last = tr == maxiter - 1;                           // the loop ends with this try whatever it gives
-            const bool ok = work && tr < maxiter && (last || !(out_of_range || fail_jac));
+            const bool ok = work && tr < maxiter && (last || !(drop_range || drop_jac));
             const unsigned long long okm = __ballot(ok);
-            // back at the rays: the first try of my group that passed, if any
+            // back at the rays: the first try of my group that was not dropped, if any
             const unsigned long long grp = (c == 64 ? okm : (okm >> (rank * c)) & ((1ull << c) - 1ull));
             const bool hit = mine && grp != 0;
             const int fj = hit ? __ffsll((long long)grp) - 1 : 0;
             const int from = mine ? rank * c + fj : lane;
-            const double g_st = shfl_d(st, from), g_ct = shfl_d(ct, from), g_u4 = shfl_d(u4, from);
+            const double g_u1 = shfl_d(u1, from), g_u2 = shfl_d(u2, from), g_u3 = shfl_d(u3, from);
             const int g_last = __shfl((int)last, from);
-            if (hit) { t_st = g_st; t_ct = g_ct; t_u4 = g_u4; t_last = g_last != 0; it += fj + 1; }
+            if (hit) { t_u1 = g_u1; t_u2 = g_u2; t_u3 = g_u3; t_last = g_last != 0; it += fj; }
             else if (mine) it += c;
             pending &= ~__ballot(hit);
         }
+        // every ray still drawing has a try that the screening let through: the tests themselves, in double precision
+        const double th = fabs(sig * (sqrt(-2.0 * log(1.0 - t_u1)) * cos(TWO_PI * t_u2)));
+        double t_st, t_ct; sincos(th, &t_st, &t_ct);
+        const bool pass1 = t_last || !(th >= 0.5 * 3.14159265358979323846 || t_u3 * fmx_own > t_st);
         const bool mine2 = (want >> lane) & 1ull;
+        const double t_u4 = rng_uniform_at(g.c0, g.c1, g.c2, g.step, g.k0, g.k1, idx0 + 4u * (uint32_t)it + 3u);
         double sp, cp; sincos(TWO_PI * t_u4, &sp, &cp);
         const V3 cand = t_ct * sn + (t_st * cp) * sx + (t_st * sp) * sy;
         const bool wrong = dot(indir, cand) >= 0;
-        if (mine2) f = cand;
-        want &= ~__ballot(mine2 && (t_last || !wrong));                   // a try that faces the wrong way is behind the ray now: on with the next ones
+        if (mine2) { it += 1; if (pass1) f = cand; }                     // that try is behind the ray now, whatever it gave
+        want &= ~__ballot(mine2 && pass1 && (t_last || !wrong));          // failed after all, or faces the wrong way: on with the next tries
     }
     if (it > 0) rng_seek(g, idx0 + 4u * (uint32_t)it);
     return f;
