@@ -1250,7 +1250,7 @@ RT_HD UnifiedOut unified_body(Rng g, Ray10 in, V3 nrm, double n1, double n2, dou
         bool crossing = true, second = false;
         V3 nuse = N;
         int guard2 = 0;
-        while (crossing && guard2++ < 2 * maxiter) {
+        while (crossing && (second || guard2++ < maxiter)) { // the cap counts passes of the reference's loop: the Fresnel step of a chosen normal (`second`) belongs to the pass that chose it
             if (!second) nuse = facet_normal(g, R.d, N, sx, sy, sig, maxiter);
             FresnelCore fc; fresnel_core(R, nuse, n1, n2, fc);
             const double s0_in = R.s0;
@@ -1418,7 +1418,7 @@ __device__ __forceinline__ UnifiedOut unified_wave(bool need, Rng g, Ray10 in, V
         if (need) {
             for (int hop = 0; hop < 3; hop++) {
                 if (inner) {
-                    if (crossing && guard2++ < 2 * maxiter) { run = true; break; }
+                    if (crossing && (second || guard2++ < maxiter)) { run = true; break; }
                     inner = false;
                     scattering = scattering && insurface;
                     if (scattering) { // .m:259-267: Lambertian re-emission from inside the surface material

@@ -171,6 +171,29 @@ def test_unified_rays_get_their_own_launch(params, n_in, n_med):
     assert np.allclose(tabs[1], ref.absorption_table, rtol=1e-10, atol=1e-9)
 
 
+@pytest.mark.parametrize("sigma,maxiter", [(1.5, 0), (3.0, 0), (1e-4, 0), (1e-7, 0), (0.3, 3), (0.1, 1)])
+def test_facet_screening_keeps_the_loop_exact(sigma, maxiter):
+    """the single-precision screening of facet-normal tries must never drop a try the loop would accept: wide lobes (most
+    tries fail the range test), needle-thin ones (the margin is relative to sigma), and loops cut short by unified_maxiter
+    (the last try is kept whatever it gives) - step counts and tallies equal the oracle's ray-by-ray loop"""
+    from raytracer_amd.RayTracer2 import RayTracer2, get_context
+    n = 50003
+    sp, rays = cases.unifiedtest_rays(n)
+    rng = np.random.default_rng(5)
+    rays[:, 0:3] += 0.4 * rng.normal(size=(n, 3)); rays[:, 3:6] = rng.normal(size=(n, 3)); rays[:, 7] = -0.3
+    sl = cases.unifiedtest(params=(sigma, .5, .6, .2, .1), n_panel_in=1.5, n_med=1.0)
+    ref = O.trace(sp, rays.copy(), sl, 10, 1e-9, 0, -1, False, True, False, seed=12, compat="matlab", unified_maxiter=maxiter)
+    c = get_context(0)
+    try:
+        c.set_option("level_min_rays", 0)
+        tab = RayTracer2(sp, rays.copy(), sl, 10, 1e-9, 0, -1, False, True, False, seed=12, compat="matlab", unified_maxiter=maxiter)[1]
+        live, scat = c.step_counts(10)
+    finally:
+        c.set_option("level_min_rays", 1 << 15)
+    assert np.array_equal(scat, ref.n_scat) and np.array_equal(live, ref.n_live)
+    assert tab.shape == ref.absorption_table.shape and np.allclose(tab, ref.absorption_table, rtol=1e-10, atol=1e-9)
+
+
 @pytest.mark.parametrize("opts", [dict(level_steps=1000, level_min_rays=0), dict(level_steps=3, level_min_rays=0)])
 def test_ray_splitting_runs_on_the_level_path(opts):
     """no-dice mode step by step: both children of every interaction go into the next step's queue (segments with room to
