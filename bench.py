@@ -79,7 +79,13 @@ def cpu_baseline(prog, origin, kw, seed, target_seconds=12.0):
                     compat="matlab", seed=seed + done, program=prog)
         t_used += time.perf_counter() - t0
         inter += int(r.n_scat.sum()); done += 1
-    return {"value": inter / t_used, "unit": "interactions/s", "cores": threads, "kind": "port",
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": inter / t_used, "unit": "interactions/s", "cores": threads, "cpu": cpu, "kind": "port",
             "sample": "%d rays (%d interactions) of the same workload through oracle/rt_oracle.c, %.1f s" % (done * n, inter, t_used)}
 
 
