@@ -6,9 +6,7 @@ root=$(cd $(dirname $0)/.. && pwd)
 src=$root/raytracer_amd/csrc
 if [ -n "$rev" ] && [ "$rev" != "WT" ]; then
   tmp=$(mktemp -d); mkdir -p $tmp/raytracer_amd/csrc $tmp/include
-  git -C $root show $rev:raytracer_amd/csrc/rt_kernels.hip > $tmp/raytracer_amd/csrc/rt_kernels.hip
-  git -C $root show $rev:raytracer_amd/csrc/rt_device.hpp > $tmp/raytracer_amd/csrc/rt_device.hpp
-  git -C $root show $rev:include/rt_mi355x.h > $tmp/include/rt_mi355x.h
+  for f in $(git -C $root ls-tree --name-only $rev raytracer_amd/csrc/ include/); do git -C $root show $rev:$f > $tmp/$f; done
   src=$tmp/raytracer_amd/csrc
 fi
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -munsafe-fp-atomics -pthread -I$root/include "$@" -o $root/build/rt_$name.so $src/rt_kernels.hip
