@@ -138,6 +138,23 @@ int rt_trace(rt_ctx* ctx, const double* start, const double* rays, int64_t n, co
  * 3..12 the ten ray columns.  The pointer is a device pointer (e.g. torch tensor.data_ptr()). */
 int rt_trace_device(rt_ctx* ctx, const double* d_soa, int64_t n, const rt_params* prm);
 
+/* rt_trace_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (it has no device and no allocator to avoid).  Tally-only
+ * single-child runs (prm->flags == RT_FLAG_SINGLECHILD, thresholds >= 0), at most RT_NOALLOC_MAX_RAYS rays and
+ * RT_NOALLOC_MAX_SCATTERS steps per call; more is refused with an error.  Every device buffer beyond the caller's
+ * inputs and outputs (ray queues, nearest hits, ray lists, counters) lives in a static device array of
+ * RT_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends; the call itself makes no
+ * hipMalloc / hipFree and touches no pooled buffer.  Outputs go to the caller's device memory: d_table
+ * [max_scatters][5][n_surf][2] (rows of steps in which nothing scattered are zero, as rt_result_table returns them;
+ * the reference's num_scatters = 1 + the last step with n_live > 0) and d_step_counts [2][max_scatters] = n_live,
+ * n_scat of rt_result_step_counts.  Blocking.  All calls on one GPU share that GPU's array: calls that overlap on one
+ * GPU (two contexts, two threads) race - serialise them. */
+#define RT_NOALLOC_MAX_RAYS 262144
+#define RT_NOALLOC_MAX_SCATTERS 4094
+#define RT_NOALLOC_SCRATCH_BYTES (80u << 20)
+int rt_trace_device_noalloc(rt_ctx* ctx, const double* d_soa, int64_t n, const rt_params* prm,
+                            double* d_table /* device */, uint64_t* d_step_counts /* device */);
+
 /* Generate n isotropic unpolarised unit-intensity rays from one point directly in HBM (the source of
  * MATLAB/Examples/RunExamples/RunSBCGeometry.m:45-68) and trace them; no host arrays involved. */
 int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm);

@@ -10,7 +10,9 @@ REC_COLS, FINAL_COLS, ROW, ATOM = 48, 32, 32, 12
 FLAG_FULL_OUTPUT, FLAG_SINGLECHILD, FLAG_FINAL_ROWS = 1, 2, 4
 COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
 
-EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device",
+NOALLOC_MAX_RAYS, NOALLOC_MAX_SCATTERS = 262144, 4094
+
+EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device", "rt_trace_device_noalloc",
            "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_record_sink", "rt_set_final_rows_device", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_table",
            "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_record_fields", "rt_split_record_fields", "rt_result_final", "rt_result_timing",
            "rt_result_timing_by_kernel", "rt_device_info")
@@ -66,6 +68,7 @@ def load():
     L.rt_set_rayleigh_lut.argtypes = [C.c_void_p, P(C.c_double), C.c_int32]
     L.rt_trace.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double), C.c_int64, P(Params)]
     L.rt_trace_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, P(Params)]
+    L.rt_trace_device_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, P(Params), C.c_void_p, C.c_void_p]
     L.rt_trace_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, P(Params)]
     L.rt_generate_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, C.c_uint64, C.c_int64, P(C.c_double), P(C.c_double)]
     L.rt_trace_camera.argtypes = [C.c_void_p, P(Camera), P(Params)]

@@ -23,6 +23,7 @@
 #include <vector>
 #include <atomic>
 #include <thread>
+#include <mutex>
 
 #define RT_HD __host__ __device__ __forceinline__
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -439,6 +440,14 @@ __global__ void __launch_bounds__(BLOCK) k_level_compact(const KArgs a) {
     for (int64_t i = threadIdx.x; i < n; i += BLOCK) { RayState q; load_queue_ray(a, base + i, q); store_ray(a.out, ob + i, q); }
 }
 
+// rt_trace_device_noalloc: the "nothing scattered" rule of python/RayTracer2.py:405-407 (a step in which no ray scatters
+// tallies nothing), which run_trace() applies on the host, applied to the caller's device table; one block per step
+__global__ void __launch_bounds__(BLOCK) k_level_finish(double* table, const unsigned long long* n_scat, int row_elems) {
+    if (n_scat[blockIdx.x] != 0ull) return;
+    double* row = table + (size_t)blockIdx.x * row_elems;
+    for (int i = threadIdx.x; i < row_elems; i += BLOCK) row[i] = 0.0;
+}
+
 // GENERIC: the program contains surfaces that fit no frame (see rt_device.hpp find_hit)
 template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HIT_WAVES : RT_HITF_WAVES) k_level_hit(const HitArgs a) {
     extern __shared__ double smem[]; // per-wave torus queues
@@ -699,6 +708,7 @@ struct rt_ctx {
     int64_t upload_chunk = (int64_t)1 << 21;
     bool stream_overlap = true; size_t stream_stage_bytes = (size_t)2 << 30, accumulate_stage_bytes = (size_t)256 << 20;
     double kernel_ms = 0; int n_launches = 0;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };    // timing events of run_trace / rt_match_endpoints: created once, so that no error path can leak one
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
@@ -706,6 +716,15 @@ struct rt_ctx {
     int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, seg_per_cu = 8;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
 };
+
+// ---- rt_trace_device_noalloc: its queues, hits, lists and counters live here instead of in hipMalloc'ed memory.
+// One copy per GPU the library runs on, held until the process ends.  The name below is a host-side stand-in, not a
+// device address: host code uses g_scratch_ptr[device] (hipGetSymbolAddress, taken in rt_init with that device
+// current), kernels get that pointer as an argument.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mutex;
 
 static std::string g_init_err;
 #define CK(call)                                                                                                           \
@@ -724,6 +743,16 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, device);
     ctx->n_cu = pr.multiProcessorCount; ctx->hbm = pr.totalGlobalMem; ctx->name = pr.gcnArchName;
     if (hipMalloc(&ctx->d_counters, 256) != hipSuccess) { g_init_err = "rt_init: hipMalloc failed"; delete ctx; return -1; }
+    for (int i = 0; i < 4; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { g_init_err = "rt_init: cannot create events"; rt_free(ctx); return -1; }
+    if (device < MAX_DEVICES) { // this GPU's copy of `scratch` (each GPU holds its own, at its own address)
+        std::lock_guard<std::mutex> lk(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            void* sp = nullptr;
+            hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+            if (se != hipSuccess || !sp) { g_init_err = std::string("rt_init: hipGetSymbolAddress(scratch): ") + hipGetErrorString(se); rt_free(ctx); return -1; }
+            g_scratch_ptr[device] = (unsigned char*)sp;
+        }
+    }
     const char* ws = getenv("RT_WORKSPACE_GB"); if (ws && atof(ws) > 0) ctx->workspace_bytes = (size_t)(atof(ws) * (double)(1ull << 30));
     const char* rf = getenv("RT_REFILL_MIN"); if (rf && atoi(rf) > 0) ctx->refill_min = atoi(rf);
     const char* bc = getenv("RT_BLOCKS_PER_CU"); if (bc && atoi(bc) > 0) ctx->blocks_per_cu = atoi(bc);
@@ -747,6 +776,7 @@ extern "C" void rt_free(rt_ctx* ctx) {
     for (auto& pb : ctx->pool) hipFree(pb.first);
     for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); if (ctx->ev_ready[s]) hipEventDestroy(ctx->ev_ready[s]); if (ctx->ev_copied[s]) hipEventDestroy(ctx->ev_copied[s]); }
     for (int s = 0; s < 2; s++) { if (ctx->in_pin[s]) hipHostFree(ctx->in_pin[s]); if (ctx->ev_up[s]) hipEventDestroy(ctx->ev_up[s]); }
+    for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -993,6 +1023,9 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     }
     if (wantfin && !fin_dev) CK(dev_alloc(ctx, b_fin, (size_t)FIN * 8 * (size_t)chunk));
     struct Stage { DevBuf dev; int64_t nrec = 0, first = 0, m = 0; bool pending = false; } stg[2];
+    // every way out of this function (the many early error returns included) waits for both streams before the DevBufs
+    // above and the stages go back to the pool: a later call must not be handed memory a kernel or a copy still uses
+    struct Quiesce { rt_ctx* c; ~Quiesce() { (void)hipStreamSynchronize(c->stream); if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); } } quiesce{ ctx };
     if (piped) {
         const size_t stage_bytes = rec_bytes * (size_t)rec_cap;
         if (!ctx->copy_stream) CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -1064,7 +1097,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     }
     const int hit_bpc = ctx->hit_blocks_per_cu > 0 ? ctx->hit_blocks_per_cu : 4096, phys_bpc = ctx->phys_blocks_per_cu > 0 ? ctx->phys_blocks_per_cu : RT_PHYS_WAVES;
 
-    hipEvent_t ev0, ev1, ev2, ev3; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1)); CK(hipEventCreate(&ev2)); CK(hipEventCreate(&ev3));
+    hipEvent_t ev0 = ctx->ev[0], ev1 = ctx->ev[1], ev2 = ctx->ev[2];
     int rc = 0;
     for (int64_t off = 0; off < n && rc == 0; off += chunk) {
         int64_t m = std::min<int64_t>(chunk, n - off);
@@ -1220,7 +1253,6 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         }
         if (wantfin && !fin_dev) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));
     }
-    hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(ev2); hipEventDestroy(ev3);
     if (piped) {
         for (int s = 0; s < 2 && rc == 0; s++) { const int t = (int)(((n + chunk - 1) / chunk + s) & 1); rc = drain(t); } // older stage first
         hipStreamSynchronize(ctx->copy_stream); // nothing of this call is in flight when its buffers go back to the pool
@@ -1251,6 +1283,94 @@ extern "C" int rt_trace_device(rt_ctx* ctx, const double* d_soa, int64_t n, cons
 }
 extern "C" int rt_trace_point_source(rt_ctx* ctx, const double origin[3], int64_t n, const rt_params* prm) {
     return run_trace(ctx, 2, nullptr, nullptr, nullptr, origin, n, prm);
+}
+
+// ---------------------------------------------------------------------------------------------- no allocation
+// rt_trace_device for callers that cannot allocate (include/rt_mi355x.h).  Tally-only single-child runs, traced by
+// the level-synchronous kernels for all K steps with fixed grids (the kernels read every count they need from device
+// memory, so the host never has to look at one): no hipMalloc / hipFree / event creation, no pooled buffer, no host
+// vector - queues, hits, the physics launches' ray lists, segment counts and counters are carved out of this GPU's
+// copy of `scratch`.  The array keeps the last call's contents: what must start at zero is cleared here.
+namespace {
+struct Carver {
+    unsigned char* p; size_t used = 0, cap;
+    void* take(size_t bytes) { void* r = p + used; used += (bytes + 255) & ~(size_t)255; return r; }
+};
+} // namespace
+extern "C" int rt_trace_device_noalloc(rt_ctx* ctx, const double* d_soa, int64_t n, const rt_params* prm, double* d_table, uint64_t* d_step_counts) {
+    if (!ctx->d_surf) { ctx->err = "rt_trace_device_noalloc: no surfaces set"; return -1; }
+    if (!d_soa || !d_table || !d_step_counts || n <= 0) { ctx->err = "Improper input to RayTracer2"; return -1; }
+    if (n > RT_NOALLOC_MAX_RAYS) { ctx->err = "rt_trace_device_noalloc: at most " + std::to_string((long long)RT_NOALLOC_MAX_RAYS) + " rays per call (the static scratch buffer holds no more); use rt_trace_device"; return -1; }
+    const int K = prm->max_scatters, S = ctx->S;
+    if (K < 1 || K > RT_NOALLOC_MAX_SCATTERS) { ctx->err = "rt_trace_device_noalloc: max_scatters must be in 1.." + std::to_string(RT_NOALLOC_MAX_SCATTERS); return -1; }
+    if (prm->flags != RT_FLAG_SINGLECHILD || prm->follow_threshold[1] < 0) { ctx->err = "rt_trace_device_noalloc: tally-only single-child runs only (flags == RT_FLAG_SINGLECHILD, thresholds >= 0)"; return -1; }
+    if (ctx->has_rayleigh && !ctx->d_lut) { ctx->err = "rt_trace: geometry has finite Rayleigh lengths but no azimuth table was set (rt_set_rayleigh_lut)"; return -1; }
+    if (ctx->device >= MAX_DEVICES || !g_scratch_ptr[ctx->device]) { ctx->err = "rt_trace_device_noalloc: no scratch buffer on this device"; return -1; }
+    CK(hipSetDevice(ctx->device));
+    const size_t lds_phys = (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 32;
+    if (lds_phys > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
+
+    // ---- segments as in run_trace(): nseg blocks, block b owns queue slots [b * seg_cap, (b + 1) * seg_cap) through all steps
+    const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * ctx->seg_per_cu, (n + 511) / 512));
+    const int64_t seg_cap = (n + nseg - 1) / nseg, q_cap = seg_cap * nseg;
+    Carver C{ g_scratch_ptr[ctx->device], 0, (size_t)RT_NOALLOC_SCRATCH_BYTES };
+    unsigned long long* counters = (unsigned long long*)C.take(256);
+    unsigned long long* lvl = (unsigned long long*)C.take(sizeof(unsigned long long) * ((size_t)K + 2));
+    uint32_t* seg = (uint32_t*)C.take(sizeof(uint32_t) * 4 * (size_t)nseg);
+    const size_t zero_bytes = C.used;                        // counters, live counts, segment counts: must start at zero
+    double* hit_l = (double*)C.take(8 * (size_t)q_cap); int32_t* hit_so = (int32_t*)C.take(4 * (size_t)q_cap);
+    uint32_t* lists = (uint32_t*)C.take(2 * 4 * (size_t)q_cap);
+    Queue q[2];
+    for (int j = 0; j < 2; j++) { q[j].cap = q_cap; q[j].d = (double*)C.take(8 * QD * (size_t)q_cap); q[j].i = (int64_t*)C.take(8 * QI * (size_t)q_cap); q[j].m = (int32_t*)C.take(4 * QM * (size_t)q_cap); }
+    if (C.used > C.cap) { ctx->err = "rt_trace_device_noalloc: scratch buffer too small for this call"; return -1; } // cannot happen within the limits above
+    const size_t telems = (size_t)K * 5 * S * 2;
+    CK(hipMemsetAsync(C.p, 0, zero_bytes, ctx->stream));
+    CK(hipMemsetAsync(d_table, 0, telems * 8, ctx->stream));
+    CK(hipMemsetAsync(d_step_counts, 0, sizeof(uint64_t) * 2 * (size_t)K, ctx->stream));
+
+    KArgs a; memset(&a, 0, sizeof a);
+    a.surf = ctx->d_surf; a.S = S; a.recs = ctx->d_recs; a.smeta = ctx->d_smeta; a.lut = ctx->d_lut; a.lut_prec = ctx->lut_n > 0 ? ctx->lut_n - 1 : 1;
+    const bool frames = ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2);
+    if (frames) { a.prog = ctx->d_prog; a.nprog = ctx->nprog_frames; } else { a.prog = ctx->d_prog + (size_t)(ctx->nprog_frames + 1) * PREC; a.nprog = ctx->nprog_generic; }
+    a.P.K = K; a.P.flags = prm->flags; a.P.compat = prm->compat; a.P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
+    a.P.base = (prm->compat & RT_COMPAT_PY_INDEX) ? 0 : 1; a.P.min_travel = prm->min_travel_length; a.P.thrA = prm->follow_threshold[0]; a.P.thrB = prm->follow_threshold[1];
+    a.P.tir = prm->tir_handling; a.P.key0 = (uint32_t)prm->seed; a.P.key1 = (uint32_t)(prm->seed >> 32);
+    a.table = d_table; a.n_live = (unsigned long long*)d_step_counts; a.n_scat = (unsigned long long*)d_step_counts + K;
+    a.head = counters; a.tail = counters + 1; a.rec_count = counters + 2; a.overflow = (int*)(counters + 3); a.prof = counters + 8;
+    a.hit_l = hit_l; a.hit_so = hit_so; a.rows_lds = 1; a.refill_min = ctx->refill_min;
+    const bool defer = ctx->has_unified && ctx->defer_unified;
+    void (*kphys)(const KArgs) = defer ? k_level_phys<FLAG_SINGLE, 1> : (ctx->has_unified ? k_level_phys<FLAG_SINGLE, 0> : k_level_phys<FLAG_SINGLE, 3>);
+    void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
+    a.defer = lists; a.dense = lists + (size_t)q_cap; a.defer_n = seg + 2 * (size_t)nseg;
+    void (*khit)(const HitArgs) = (!frames || ctx->frames_have_generic) ? k_level_hit<true> : k_level_hit<false>;
+    CK(hipFuncSetAttribute((const void*)kphys, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
+    if (defer) CK(hipFuncSetAttribute((const void*)kphys2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
+    HitArgs ha; memset(&ha, 0, sizeof ha);
+    ha.prog = a.prog; ha.nprog = a.nprog; ha.recs = ctx->d_recs; ha.surf = ctx->d_surf; ha.smeta = ctx->d_smeta; ha.S = S;
+    ha.min_travel = a.P.min_travel; ha.base = a.P.base; ha.compat = a.P.compat; ha.hit_l = hit_l; ha.hit_so = hit_so;
+    ha.seg_cap = seg_cap; ha.split = (int)((seg_cap + BLOCK - 1) / BLOCK); // one 256-ray tile per block; tiles behind a segment's live count have nothing to do
+    a.seg_cap = seg_cap; a.seg_fill = seg_cap;
+    uint32_t* sg[2] = { seg, seg + nseg };
+
+    // initial rays -> queue 1 (step 0 writes queue 0)
+    a.mode = 0; a.in_d = d_soa; a.in_stride = n; a.n_in = n; a.ray_id_base = prm->ray_id_base; a.slot_base = prm->ray_id_base;
+    a.out = q[1]; a.seg_out = sg[1];
+    hipLaunchKernelGGL(k_level_init<0>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, a);
+    a.mode = 1; a.in_d = q[1].d; a.in_i = q[1].i; a.in_m = q[1].m; a.in_stride = q_cap;
+    int cur = 0, sin = 1;
+    for (int k = 0; k < K; k++) {
+        a.step = k; a.n_in = n; a.out = q[cur]; a.tail = lvl + k + 1; a.seg_in = sg[sin]; a.seg_out = sg[sin ^ 1];
+        ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = q_cap; ha.n_in = n; ha.seg_in = sg[sin];
+        hipLaunchKernelGGL(khit, dim3((unsigned)(nseg * ha.split)), dim3(BLOCK), (size_t)TQ_DOUBLES * 8, ctx->stream, ha);
+        hipLaunchKernelGGL(kphys, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
+        if (defer) hipLaunchKernelGGL(kphys2, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
+        a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m;
+        cur ^= 1; sin ^= 1;
+    }
+    hipLaunchKernelGGL(k_level_finish, dim3((unsigned)K), dim3(BLOCK), 0, ctx->stream, d_table, (const unsigned long long*)d_step_counts + K, 5 * S * 2);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 namespace {
 int upload_camera(rt_ctx* ctx, const rt_camera* cam, int64_t* n_pix) {

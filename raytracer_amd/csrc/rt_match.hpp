@@ -294,7 +294,7 @@ extern "C" int rt_match_endpoints(rt_ctx* ctx, const double* cam_rows, int64_t n
     if (int rc = match_alloc_pts(ctx, cam, b_cpts, b_cslot, std::max<int64_t>(n_cam, 1))) return rc;
     if (int rc = match_alloc_pts(ctx, led, b_lpts, b_lslot, n_led)) return rc;
     cam.n = n_cam;
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1];
     CK(hipEventRecord(e0, st));
     unsigned long long* d_stats = (unsigned long long*)b_stats.p;
     if (n_cam) {
@@ -307,7 +307,7 @@ extern "C" int rt_match_endpoints(rt_ctx* ctx, const double* cam_rows, int64_t n
     CK(hipGetLastError()); ctx->n_launches++;
     unsigned long long stats[3];
     CK(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-    if (stats[1]) { hipEventDestroy(e0); hipEventDestroy(e1); ctx->err = "rt_match_endpoints: end points further than 2^20 * max_dist from the origin"; return -1; }
+    if (stats[1]) { ctx->err = "rt_match_endpoints: end points further than 2^20 * max_dist from the origin"; return -1; }
     const int64_t n_on = (int64_t)stats[0]; const double occ0 = (double)std::max<unsigned long long>(stats[2], 1);
     // leaf level: end points lie on surfaces, so a cell's load falls by about 4 per level; aim at a handful per leaf
     int leaf = 0;
@@ -361,6 +361,5 @@ extern "C" int rt_match_endpoints(rt_ctx* ctx, const double* cam_rows, int64_t n
     }
     CK(hipStreamSynchronize(st));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ctx->kernel_ms = ms;
-    hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;
 }
