@@ -40,6 +40,11 @@ class _Base(object):
             return args[0]._sum(*args[1:], **kwargs)
         if name == "all" and isinstance(args[0], Bool):
             return args[0]
+        if name == "size":   # `np.size(p, 0)` as the second argument of reshape (python/createGeometry.py:1105 and every surface of that file)
+            axis = args[1] if len(args) > 1 else kwargs.get("axis")
+            return 3 if (isinstance(args[0], Vec) and axis == 1) else 1
+        if name == "shape":
+            return args[0].shape
         raise BoundsCompileError("numpy function %s is not supported inside inbounds_function" % name)
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):

@@ -811,6 +811,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "level_min_rays") ctx->level_min_rays = (int64_t)value;
     else if (k == "hit_blocks_per_cu") ctx->hit_blocks_per_cu = (int)value;
     else if (k == "hit_split") ctx->hit_split = (int)value;
+    else if (k == "seg_per_cu") { if (!(value >= 1 && value <= 64)) { ctx->err = "rt_set_option: seg_per_cu must be in 1..64"; return -1; } ctx->seg_per_cu = (int)value; }
     else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
     else if (k == "defer_unified") ctx->defer_unified = value != 0;
     else if (k == "match_max_level") ctx->match_max_level = std::min(10, std::max(0, (int)value));
