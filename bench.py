@@ -37,8 +37,8 @@ def flop_per_interaction(table):
 def build_workload(name):
     from raytracer_amd import geometries as G
     from raytracer_amd import table as T
-    if name in ("sbc_full_mc", "sbc_full_mc_blackcones"):
-        sl = G.create_arbc_geometry(G.sbc_full_mc_specs(black_cones=name.endswith("blackcones")))
+    if name in ("sbc_full_mc", "sbc_full_mc_blackcones", "sbc_full_mc_diffuse"):  # _diffuse: SURVEY 8d config 5 with 'diffuse' reflectors
+        sl = G.create_arbc_geometry(G.sbc_full_mc_specs(black_cones=name.endswith("blackcones"), reflector="diffuse" if name.endswith("diffuse") else "unified"))
         origin = (0.0, 0.0, 10.0)
         kw = dict(K=100, min_travel=1e-6, thr=(1e-4, 1e-4), tir=-1.0)
     elif name == "arbc_camera":  # camera rays through the jar, python/BubbleImageCreator.py:129

@@ -255,13 +255,19 @@ def create_sbc_geometry(geospecs=None):
     return sl
 
 
-def sbc_full_mc_specs(black_cones=False):
+def sbc_full_mc_specs(black_cones=False, reflector="unified"):
     """jar geometry with Rayleigh/absorption lengths of CreateSBCGeometry.m:40-41 in the target
     fluid and reflective (UNIFIED, rough conductor, 10 % absorption) reflector/diffuser surfaces instead of the black
     ones: the cylinder, its cone and the cones around the jar.  In single-child mode a reflector hit scales the ray's
     intensity by 0.9 instead of ending it, so light keeps bouncing between jar and reflector until the intensity
     threshold or max_scatters ends it (about 87 interactions per ray at K = 100, threshold 1e-4).
     black_cones=True leaves the cones black as in the MATLAB file: nearly every ray ends on the top cone after 3-4
-    interactions (the workload of the builds r1a-r1f in DESIGN.md)."""
+    interactions (the workload of the builds r1a-r1f in DESIGN.md).
+    reflector="diffuse": config 5 as SURVEY 8d words it - the reflector surfaces are of surface_type 'diffuse'
+    (MATLAB/RayTracer2.m:394-415: Lambertian re-draw of the normal, then a mirror step off a conductor), same 10 %
+    absorption."""
+    if reflector == "diffuse":
+        return ArBCSpecs(target_rayleigh=29.0, target_abslength=300.0, reflector_type="diffuse", reflector_absorption=0.1,
+                         reflector_n_inside=np.inf, reflector_all=not black_cones)
     return ArBCSpecs(target_rayleigh=29.0, target_abslength=300.0, reflector_type="unified", reflector_absorption=0.1,
                      reflector_unifiedparams=[0.1, 0.0, 0.3, 0.2, 0.05], reflector_n_inside=np.inf, reflector_all=not black_cones)
