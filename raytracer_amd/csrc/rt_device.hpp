@@ -1635,9 +1635,12 @@ struct LeanBounce {
 // UNI = 1: the kernel pass that sees nothing but rays ending on UNIFIED surfaces carries the rough-surface loop in
 // line, with the register budget that needs; UNI = 2: the pass that has put those rays aside carries no UNIFIED code at
 // all; UNI = 0 (everywhere else): out of line.
-// NORAY (with UNI = 2): the caller has also put aside the rays that scatter in the bulk before they reach their surface
+// NORAY (with UNI = 2): 1 = the caller has also put aside the rays that scatter in the bulk before they reach their surface
 // (level_ray_scatters() below, the same arithmetic): every ray that comes here scatters on its surface, no Rayleigh code.
-template <int UNI = 0, bool NORAY = false> RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b, bool act = true) {
+// 2 = no Rayleigh code either, but the draw of python/RayTracer2.py:409 is made here: a ray that scatters in the bulk
+// comes back untouched with b.scat = 2, for the caller to hand to the launch that has that code (which starts the
+// ray's stream afresh and makes the same draw).
+template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& G, const Prm& P, const RayState& q, const Hit& h, LeanBounce& b, bool act = true) {
     Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
     b.scat = 0; b.surf_sc = 0; b.fa = 0; b.smix_next = 0; b.six_next = 0; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = 0;
@@ -1663,8 +1666,9 @@ template <int UNI = 0, bool NORAY = false> RT_HD void bounce_phys_single(const G
     b.scat = 1;
     double l_bulk = INFINITY;
     if (rayl1 < INFINITY) l_bulk = -rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
-    const bool surf_sc = (UNI == 2 && NORAY) ? true : (h.l <= l_bulk);
+    const bool surf_sc = (UNI == 2 && NORAY == 1) ? true : (h.l <= l_bulk);
     b.surf_sc = surf_sc;
+    if constexpr (UNI == 2 && NORAY == 2) { if (!surf_sc) { b.scat = 2; return; } }
     const bool uni_sc = UNI != 2 && surf_sc && st == ST_UNIFIED, nor_sc = surf_sc && !uni_sc;
     double l = h.l;
     if (!surf_sc) { b.six_next = 0; l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
@@ -1706,7 +1710,7 @@ template <int UNI = 0, bool NORAY = false> RT_HD void bounce_phys_single(const G
             if (goodcut) ch.d = (c.sin_t >= 1) ? -ny : (-c.cos_t) * c.n - c.sin_t * ny;
         }
         ch.s0 *= f; ch.s1 *= f; ch.s2 *= f; ch.s3 *= f;
-    } else if constexpr (!(UNI == 2 && NORAY)) {
+    } else if constexpr (!(UNI == 2 && NORAY != 0)) {
         Ray10 r;
         bool ray_sc = true;
         if constexpr (UNI != 2) {

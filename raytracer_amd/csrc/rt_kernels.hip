@@ -184,6 +184,18 @@ __device__ __forceinline__ void store_ray(const Queue& Q, int64_t idx, const Ray
     Q.m[idx] = (int32_t)c.hash; Q.m[st + idx] = c.k; Q.m[2 * st + idx] = c.smix_last; Q.m[3 * st + idx] = c.six_last; Q.m[4 * st + idx] = c.flags;
 }
 
+// tally-only single-child runs (the level kernels' lean step): parent slot and flags mean nothing there (every ray is its own
+// primary and never marked reflected) and the step is a kernel argument, so the queue record is 124 bytes instead of 140
+__device__ __forceinline__ void store_ray_lean(const Queue& Q, int64_t idx, const RayState& c) {
+    double* d = Q.d; const int64_t st = Q.cap;
+    d[0 * st + idx] = c.p.x; d[1 * st + idx] = c.p.y; d[2 * st + idx] = c.p.z;
+    d[3 * st + idx] = c.r.d.x; d[4 * st + idx] = c.r.d.y; d[5 * st + idx] = c.r.d.z;
+    d[6 * st + idx] = c.r.pol.x; d[7 * st + idx] = c.r.pol.y; d[8 * st + idx] = c.r.pol.z;
+    d[9 * st + idx] = c.r.s0; d[10 * st + idx] = c.r.s1; d[11 * st + idx] = c.r.s2; d[12 * st + idx] = c.r.s3;
+    Q.i[idx] = c.ray_id;
+    Q.m[idx] = (int32_t)c.hash; Q.m[2 * st + idx] = c.smix_last; Q.m[3 * st + idx] = c.six_last;
+}
+
 // slot allocation for the lanes that are active here: one atomic per wave, consecutive slots in lane order
 __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* counter) {
     unsigned long long act = __ballot(1);
@@ -406,6 +418,9 @@ template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_b
 #ifndef RT_P1_WAVES
 #define RT_P1_WAVES RT_PHYS_WAVES /* the common launch of a step with two (k_level_phys PASS 1) */
 #endif
+#ifndef RT_LEAN_WAVES
+#define RT_LEAN_WAVES 2 /* the software-pipelined tally-only launches: a second queue record per lane in flight */
+#endif
 #ifndef RT_UNI_WAVES
 #define RT_UNI_WAVES 2 /* the pass that runs the UNIFIED rough-surface loop in line */
 #endif
@@ -437,7 +452,12 @@ __global__ void __launch_bounds__(BLOCK) k_level_compact(const KArgs a) {
     if (threadIdx.x == 0) s_base = atomicAdd(a.tail, (unsigned long long)n);
     __syncthreads();
     const int64_t ob = (int64_t)s_base;
-    for (int64_t i = threadIdx.x; i < n; i += BLOCK) { RayState q; load_queue_ray(a, base + i, q); store_ray(a.out, ob + i, q); }
+    const bool lean = a.P.flags == FLAG_SINGLE; // lean records (store_ray_lean) leave these out
+    for (int64_t i = threadIdx.x; i < n; i += BLOCK) {
+        RayState q; load_queue_ray(a, base + i, q);
+        if (lean) { q.k = a.step; q.parent = -1; q.flags = RF_PRIMARY; }
+        store_ray(a.out, ob + i, q);
+    }
 }
 
 // rt_trace_device_noalloc: the "nothing scattered" rule of python/RayTracer2.py:405-407 (a step in which no ray scatters
@@ -480,8 +500,15 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
 // PASS 2: the listed rays, children appended behind those of pass 1; for CF == FLAG_SINGLE (tallies only) the wave
 // works through the UNIFIED model together (unified_wave), otherwise every lane runs it in line.
 // PASS 3: PASS 0 for a geometry without UNIFIED surfaces (no such code in the kernel).
-template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS == 2 ? RT_UNI_WAVES : (PASS == 1 ? RT_P1_WAVES : RT_PHYS_WAVES)) k_level_phys(const KArgs a) {
+#define RT_PHYS_BOUNDS(CF, PASS) (PASS == 2 ? RT_UNI_WAVES : (CF == FLAG_SINGLE ? RT_LEAN_WAVES : (PASS == 1 ? RT_P1_WAVES : RT_PHYS_WAVES)))
+template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS_BOUNDS(CF, PASS)) k_level_phys(const KArgs a) {
     extern __shared__ double smem[];
+#ifdef RT_PROFILE
+    long long pp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; long long pt0 = (long long)__builtin_readcyclecounter(), pt1;
+#define PP_ADD(i) { pt1 = (long long)__builtin_readcyclecounter(); pp[i] += pt1 - pt0; pt0 = pt1; }
+#else
+#define PP_ADD(i)
+#endif
     if constexpr (PASS == 2) { if (a.defer_n[2 * blockIdx.x] + a.defer_n[2 * blockIdx.x + 1] == 0) return; } // nothing put aside in this segment
     // LDS image: surface rows (per-lane gather of the winning surface) | this step's tally row | step counters
     double* s_surf = smem;
@@ -493,6 +520,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     const uint32_t child0 = PASS == 2 ? a.seg_out[blockIdx.x] : 0u;
     if (threadIdx.x < 6) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred (UNIFIED), dense, deferred (bulk scatters)
     __syncthreads();
+    PP_ADD(0)
     Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr, (udptr)a.prog, a.nprog };
     const Prm P = a.P;
     const bool full = (CF & FLAG_FULL) && (P.flags & FLAG_FULL), wantfin = (CF & FLAG_FINAL) && (P.flags & FLAG_FINAL);
@@ -505,28 +533,96 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
     int64_t n = seg0 + (PASS == 2 ? nfp + nb : (int64_t)a.seg_in[blockIdx.x]);
     constexpr bool listed = PASS == 2 || PASS == 1;
     if constexpr (PASS == 1) { // sort the segment's rays into the two lists; this launch then takes the dense one
-        for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
-            const int64_t idx = base + lane_id();
-            if (idx < n) {
-                const int so = a.hit_so[idx];
-                bool heavy = so >= 0 && (int)s_surf[(so >> 2) * ROW + 1] == ST_UNIFIED, bulk = false;
-                if (!heavy && so >= 0) { // bulk scatter before the surface: the other launch has the Rayleigh code
-                    const double* row = s_surf + (so >> 2) * ROW;
-                    if ((((so & 3) - 1) < 0 ? row[21] : row[20]) < INFINITY) {
-                        Hit h; h.l = a.hit_l[idx]; h.surf = so >> 2; h.orient = (so & 3) - 1;
-                        heavy = bulk = level_ray_scatters(G, P, a.in_i[idx], (uint32_t)a.in_m[idx], k, h);
-                    }
-                }
+        // Only the surface type decides here.  Whether a ray scatters in the bulk before it reaches its surface is found
+        // out by the physics step itself (bounce_phys_single<2, 2>: it has to make that draw anyway), which then puts the
+        // ray on the other launch's list from the back.  (Making the draw here cost a Philox block and a logarithm per
+        // ray in a scattering medium a second time: the sort was 28 % of this launch's wave-cycles, r2j.)
+        constexpr int SORT_U = 4;
+        for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += SORT_U * BLOCK) {
+            int so[SORT_U];
+#pragma unroll
+            for (int u = 0; u < SORT_U; u++) { const int64_t idx = base + u * BLOCK + lane_id(); so[u] = idx < n ? a.hit_so[idx] : -2; }
+#pragma unroll
+            for (int u = 0; u < SORT_U; u++) {
+                if (so[u] == -2) continue;
+                const int64_t idx = base + u * BLOCK + lane_id();
+                const bool heavy = so[u] >= 0 && (int)s_surf[(so[u] >> 2) * ROW + 1] == ST_UNIFIED;
                 // the list of the other launch: UNIFIED rays from the front, bulk scatters from the back, so that its waves are of one kind
-                if (heavy && bulk) a.defer[seg0 + a.seg_cap - 1 - (int64_t)wave_alloc_lds(&s_cnt[5])] = (uint32_t)(idx - seg0);
-                else if (heavy) a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
+                if (heavy) a.defer[seg0 + (int64_t)wave_alloc_lds(&s_cnt[3])] = (uint32_t)(idx - seg0);
                 else a.dense[seg0 + (int64_t)wave_alloc_lds(&s_cnt[4])] = (uint32_t)(idx - seg0);
             }
         }
+        PP_ADD(1)
         __syncthreads();
+        PP_ADD(2)
         n = seg0 + (int64_t)s_cnt[4];
     }
     const uint32_t* list = PASS == 2 ? a.defer : a.dense;
+    if constexpr (CF == FLAG_SINGLE && PASS != 2) {
+        // Tally-only step of the rays that take the common path, software-pipelined: the queue record of the ray a lane
+        // works on next (and the list entry of the one after) is requested before the physics of the current one starts, so
+        // the ~2 us an HBM round trip takes under load pass during ~1 500 vector instructions instead of in front of them.
+        // (Measured on the unpipelined loop, r2d: its waves spent 55 % of their cycles in s_waitcnt at 3 waves/SIMD.)
+        struct Raw { double v[QD]; double hl; int64_t ray_id; uint32_t hash; int32_t smix_last, six_last, so; };
+        const double* D = a.in_d; const int64_t st = a.in_stride; const int lane = lane_id();
+        // list entries travel as loaded (no arithmetic on them until the iteration that needs the slot: a use would make the wave wait for the load)
+        auto entry_of = [&](int64_t base) -> uint32_t { const int64_t i = base + lane; return (listed && i < n) ? list[i] : 0u; };
+        auto slot_of = [&](int64_t base, uint32_t e) -> int64_t { const int64_t i = base + lane; if (i >= n) return -1; return listed ? seg0 + (int64_t)e : i; };
+        auto fetch = [&](int64_t idx, Raw& r) {
+            if (idx < 0) return;
+            r.so = a.hit_so[idx]; r.hl = a.hit_l[idx];
+#pragma unroll
+            for (int f = 0; f < QD; f++) r.v[f] = D[f * st + idx];
+            r.ray_id = a.in_i[idx]; r.hash = (uint32_t)a.in_m[idx]; r.smix_last = a.in_m[2 * st + idx]; r.six_last = a.in_m[3 * st + idx];
+        };
+        const int64_t first = seg0 + (threadIdx.x & ~63);
+        int64_t idx1 = slot_of(first, entry_of(first));
+        uint32_t e2 = entry_of(first + BLOCK);
+        Raw nxt = {}; fetch(idx1, nxt);
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), as an instruction the compiler's own wait-count pass sees (inline asm is opaque to it) */ // the loop is entered as it is re-entered: nothing in flight (or the compiler makes every iteration wait at the top for what only the first has pending)
+        for (int64_t base = first; base < n; base += BLOCK) {
+            const Raw cur = nxt; const int64_t idx = idx1;
+            idx1 = slot_of(base + BLOCK, e2);
+            fetch(idx1, nxt);
+            e2 = entry_of(base + 2 * BLOCK); // behind the record's loads: the wave's memory counter is in order, and what waits for them must not wait for this
+            RayState c; int64_t at = -1;
+            if (idx >= 0) {
+                RayState q;
+                q.p = V3{ cur.v[0], cur.v[1], cur.v[2] }; q.r.d = normalized_if(V3{ cur.v[3], cur.v[4], cur.v[5] }); q.r.pol = V3{ cur.v[6], cur.v[7], cur.v[8] };
+                q.r.s0 = cur.v[9]; q.r.s1 = cur.v[10]; q.r.s2 = cur.v[11]; q.r.s3 = cur.v[12];
+                q.ray_id = cur.ray_id; q.parent = -1; q.hash = cur.hash; q.k = k; q.smix_last = cur.smix_last; q.six_last = cur.six_last; q.flags = RF_PRIMARY;
+                Hit h; h.l = cur.hl; h.surf = cur.so < 0 ? -1 : (cur.so >> 2); h.orient = cur.so < 0 ? 0 : (cur.so & 3) - 1;
+                LeanBounce b;
+#if defined(RT_EXP) && (RT_EXP & 4)
+                b.scat = 1; b.surf_sc = 1; b.fa = 1; b.smix_next = h.surf + 1; b.six_next = h.surf + 1; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = q.r.s0; b.p = q.p + h.l * q.r.d; b.child = q.r; b.inc_intensity = q.r.s0;
+#else
+                if constexpr (PASS == 1) bounce_phys_single<2, 2>(G, P, q, h, b, true);
+                else bounce_phys_single<PASS == 3 ? 2 : 0>(G, P, q, h, b, true);
+#endif
+                if (PASS == 1 && b.scat == 2) a.defer[seg0 + a.seg_cap - 1 - (int64_t)wave_alloc_lds(&s_cnt[5])] = (uint32_t)(idx - seg0); // scatters in the bulk: the other launch's
+                else atomicAdd(&s_cnt[0], 1u);
+                if (PASS == 1 && b.scat == 2) {}
+                else if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
+                else {
+                    atomicAdd(&s_cnt[1], 1u);
+#if !(defined(RT_EXP) && (RT_EXP & 1))
+                    if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);
+                    tally_add(t, s_tab, 0, 1, b.smix_next, b.bulk_abs);
+                    tally_add(t, s_tab, 0, b.fa ? 4 : 3, b.smix_next, b.s0_child);
+#endif
+                    if (k + 1 < P.K && b.fa) { c = lean_child(q, b); at = seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]); } // at most one child per ray: the segment cannot overflow
+                }
+            }
+            // The wave's memory counter counts loads and stores together, in order.  The next record's loads are older than
+            // this child's stores only if the stores come behind the point that waits for them; placed in front, every
+            // iteration would wait for its own stores to be acknowledged.  So: wait here (the loads have had the whole
+            // step to land; the previous child's stores are older still), then store.
+            PP_ADD(3)
+            __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), as an instruction the compiler's own wait-count pass sees (inline asm is opaque to it) */
+            PP_ADD(4)
+            if (at >= 0) store_ray_lean(a.out, at, c);
+        }
+    } else
     for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
         int64_t idx = base + lane_id();
         // PASS 2: the wave works together on the rough-surface loop (unified_wave), so all 64 lanes go through the step;
@@ -550,7 +646,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
             if constexpr (CF == FLAG_SINGLE) { // tallies only: one child, built after the dice
                 LeanBounce b;
                 // PASS 1 working through its list: neither UNIFIED surfaces nor bulk scatters come here (the sort above decided)
-                if constexpr (PASS == 1) bounce_phys_single<2, true>(G, P, q, h, b, act);
+                if constexpr (PASS == 1) bounce_phys_single<2, 1>(G, P, q, h, b, act);
                 else bounce_phys_single<PASS == 2 ? 1 : (PASS == 3 ? 2 : 0)>(G, P, q, h, b, act);
                 if (!act) {}
                 else if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
@@ -561,7 +657,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
                     tally_add(t, s_tab, 0, b.fa ? 4 : 3, b.smix_next, b.s0_child);
                     if (k + 1 < P.K && b.fa) {
                         RayState c = lean_child(q, b);
-                        store_ray(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c); // at most one child per ray: the segment cannot overflow
+                        store_ray_lean(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c); // at most one child per ray: the segment cannot overflow
                     }
                 }
             } else {
@@ -602,7 +698,9 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
             }
         }
     }
+    PP_ADD(3)
     __syncthreads();
+    PP_ADD(5)
     double* row = a.table + (size_t)k * ntab;
     for (int i = threadIdx.x; i < ntab; i += BLOCK) { double v = s_tab[i]; if (v != 0.0) atomicAdd(&row[i], v); }
     if (threadIdx.x == 0) {
@@ -613,6 +711,10 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, PASS ==
         if (kept > child0) atomicAdd(a.tail, (unsigned long long)(kept - child0));
         if constexpr (PASS == 1) { a.defer_n[2 * blockIdx.x] = s_cnt[3]; a.defer_n[2 * blockIdx.x + 1] = s_cnt[5]; }
     }
+#ifdef RT_PROFILE
+    PP_ADD(6)
+    if (lane_id() == 0 && a.prof) for (int i = 0; i < 7; i++) atomicAdd(&a.prof[(PASS == 2 ? 8 : 0) + i], (unsigned long long)pp[i]);
+#endif
 }
 
 __global__ void k_aos_to_soa(const double* start, const double* rays, int64_t n, double* soa) {
@@ -1178,7 +1280,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             }
             if (rc) break;
             if (go && live > 0 && k0 < K) { // hand-over: the persistent kernel reads a dense queue
-                a.seg_in = seg[sin]; a.out = q[cur]; a.tail = ctx->d_counters + 1;
+                a.seg_in = seg[sin]; a.out = q[cur]; a.tail = ctx->d_counters + 1; a.step = k0;
                 hipLaunchKernelGGL(k_level_compact, dim3((unsigned)nseg), dim3(BLOCK), 0, ctx->stream, a);
                 CK(hipGetLastError());
                 CK(hipMemsetAsync(ctx->d_counters + 1, 0, 8, ctx->stream));
