@@ -34,6 +34,16 @@ def flop_per_interaction(table):
     return float(sum(FLOP_SHAPE[int(s)] for s in table[:, 0]) + FLOP_PHYSICS)
 
 
+def csrc_sha256():
+    """hash of the kernel sources: profiles/counters.json is only believed if it was made from these"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "raytracer_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build_workload(name):
     from raytracer_amd import geometries as G
     from raytracer_amd import table as T
@@ -145,6 +155,7 @@ def main():
 
     by_kernel = [[0.0, 0], [0.0, 0], [0.0, 0]]  # k_trace, k_level_hit, k_level_phys: ms, launches
     hit_units = [0]
+    table_sum = [None]
 
     def step(i):
         prm = ctx.params(kw["K"], flags, 0, kw["min_travel"], kw["thr"], kw["tir"], a.seed, (rank * (a.steps + a.warmup) + i) * a.rays)
@@ -155,6 +166,11 @@ def main():
         else:
             ctx._check(ctx.L.rt_trace_point_source(ctx.h, org, a.rays, C.byref(prm)))
         live, scat = ctx.step_counts(kw["K"])
+        if dist is not None:  # the one collective of the path: the tallies of all ranks (multigpu.sharded_trace does the same)
+            tab = np.zeros((kw["K"], 5, S, 2)); t_ = ctx.results(False, False, a.rays)["table"]; tab[:t_.shape[0]] = t_
+            tt = torch.from_numpy(tab).to("cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            table_sum[0] = float(tt.sum())
         ms = C.c_double(); nl = C.c_int32(); ctx.L.rt_result_timing(ctx.h, C.byref(ms), C.byref(nl))
         bk = (C.c_double * 3)(); bn = (C.c_int32 * 3)(); ctx.L.rt_result_timing_by_kernel(ctx.h, bk, bn)
         for j in range(3):
@@ -202,15 +218,21 @@ def main():
             ach = path
             dom = {"kernel": "k_trace", "launches": by_kernel[0][1], "avg_launch_ms": by_kernel[0][0] / max(by_kernel[0][1], 1),
                    "units_per_launch": inter / max(by_kernel[0][1], 1), "flop_per_unit": fpi, "unit_name": "interaction"}
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes of the same command (tools/profile_traffic.sh), bytes per launch
-        if os.path.exists(tpath):
+        # Counter-measured figures of the dominant kernel come from rocprofv3 --pmc passes of this same command
+        # (tools/profile_counters.sh -> profiles/counters.json); they are used only if that file was made from the kernel
+        # sources as they are now (sha256 of raytracer_amd/csrc) on this workload, and are null otherwise.
+        traffic = counter_tflops = valu_issue_frac = None
+        cpath = os.path.join(ROOT, "profiles", "counters.json")
+        if os.path.exists(cpath):
             try:
-                t = json.load(open(tpath))
-                if t.get("rays_per_step") == a.rays and t.get("workload") == a.workload:
-                    traffic = t["kernels"].get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+                t = json.load(open(cpath))
+                if t.get("workload") == a.workload and t.get("src_sha256") == csrc_sha256():
+                    kk = t["kernels"].get(dom["kernel"], {})
+                    traffic = kk.get("hbm_bytes_per_unit") * dom["units_per_launch"] if kk.get("hbm_bytes_per_unit") is not None else None
+                    counter_tflops = kk.get("fp64_flop_per_unit") * dom["units_per_launch"] / (dom["avg_launch_ms"] / 1e3) / 1e12 if kk.get("fp64_flop_per_unit") is not None else None
+                    valu_issue_frac = kk.get("valu_issue_frac")
             except Exception:
-                traffic = None
+                traffic = counter_tflops = valu_issue_frac = None
         out = {
             "metric": "ray-surface interactions/sec (node) on SBC geometry", "value": inter_all / dt, "unit": "interactions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
@@ -221,13 +243,18 @@ def main():
                        "rays_per_step_per_gpu": a.rays, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                              "traffic": traffic,
-                              "note": "FP64 vector path: no dense contraction (MFMA unused), HBM traffic is below the roof (profiles/traffic.json); "
-                                      "algorithmic flop convention of SURVEY.md 8a/8d"}, **dom),
+                              "traffic": traffic, "counter_tflops": counter_tflops, "valu_issue_frac": valu_issue_frac,
+                              "note": "achieved/frac follow the ALGORITHMIC flop convention of SURVEY.md 8a/8d (every surface counted for every ray; the frame "
+                                      "program exists to skip most of that work, so this is not executed work). counter_tflops = FP64 flops the kernel executed "
+                                      "(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2) per second, valu_issue_frac = SQ_ACTIVE_INST_VALU cycles / "
+                                      "(GRBM_GUI_ACTIVE x SIMDs), traffic = HBM bytes per launch (TCC_EA0 read/write requests): profiles/counters.json, "
+                                      "null when that file is not from these kernel sources. No dense contraction: MFMA unused"}, **dom),
             "roofline_path": {"achieved": path, "frac": path / FP64_VALU_PEAK_TFLOPS, "flop_per_interaction": fpi, "kernel_ms_per_step": kms / a.steps,
                               "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
                                             for j, n in enumerate(names)}},
         }
+        if table_sum[0] is not None:
+            out["config"]["allreduced_table_sum_last_step"] = table_sum[0]
         if not a.no_cpu_baseline and world == 1 and cam is None:
             out["cpu_baseline"] = cpu_baseline(prog, origin, kw, a.seed)
         print(json.dumps(out))

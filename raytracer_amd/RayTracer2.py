@@ -80,10 +80,14 @@ class Context(object):
             self._check(self.L.rt_set_rayleigh_lut(self.h, _dp(lut), lut.shape[0])); self._lut_set = True
 
     def set_surfaces(self, surfacelist, nobulk=False):
+        """upload the geometry unless it is the one already there.  The key holds the surfaces' own values and, for every
+        inbounds_function, its code and whatever it closes over or reads from its globals (a lambda whose closed-over bound
+        changes keeps its id); the surfaces and functions are kept referenced, so that no id in the key can be recycled."""
         key = (tuple(id(s) for s in surfacelist), nobulk, tuple(_surface_fingerprint(s) for s in surfacelist))
         if key != self._geom_key:
             self.set_program(*_table.compile_surfaces(surfacelist, nobulk=nobulk))
             self._geom_key = key
+            self._geom_refs = (list(surfacelist), [getattr(s, "inbounds_function", None) for s in surfacelist])
 
     def params(self, K, flags, compat, min_travel, thr, tir, seed, ray_id_base, unified_maxiter=0):
         p = _lib.Params()
@@ -156,6 +160,40 @@ class Context(object):
         return live, scat
 
 
+def _value_print(v, depth=0):
+    """hashable digest of a value a bounds lambda may depend on"""
+    if isinstance(v, (int, float, complex, bool, str, bytes, type(None))):
+        return v
+    if isinstance(v, np.generic):
+        return v.item()
+    if isinstance(v, np.ndarray):
+        return ("nd", v.shape, v.dtype.str, v.tobytes()) if v.size <= 4096 else ("nd-big", id(v), v.shape)
+    if isinstance(v, (list, tuple)) and depth < 3:
+        return tuple(_value_print(x, depth + 1) for x in v)
+    if callable(v) and depth < 3:
+        return _function_print(v, depth + 1)
+    return ("obj", id(v))
+
+
+def _function_print(fn, depth=0):
+    code = getattr(fn, "__code__", None)
+    if code is None:
+        return ("callable", id(fn))
+    cells = tuple(_value_print(c.cell_contents, depth) if _cell_set(c) else None for c in (fn.__closure__ or ()))
+    g = getattr(fn, "__globals__", {})
+    names = tuple((n, _value_print(g[n], depth)) for n in code.co_names if n in g and not isinstance(g[n], type(np)))
+    consts = tuple(_value_print(c, depth) if not hasattr(c, "co_code") else c.co_code for c in code.co_consts)
+    return (code.co_code, consts, cells, names, _value_print(getattr(fn, "__defaults__", None), depth))
+
+
+def _cell_set(c):
+    try:
+        c.cell_contents
+        return True
+    except ValueError:
+        return False
+
+
 def _surface_fingerprint(s):
     pl = getattr(s, "param_list", None)
     try:
@@ -166,7 +204,7 @@ def _surface_fingerprint(s):
     return (getattr(s, "shape", None), plf, getattr(s, "n_outside", None), getattr(s, "n_inside", None), getattr(s, "surface_type", None),
             getattr(s, "absorption", None), None if up is None else tuple(np.asarray(up, float).ravel()),
             tuple(None if getattr(s, n, None) is None else float(np.asarray(getattr(s, n)).ravel()[0]) if np.size(getattr(s, n)) else None for n in _table.BULK_PROPS),
-            id(getattr(s, "inbounds_function", None)))
+            _function_print(getattr(s, "inbounds_function", None)) if getattr(s, "inbounds_function", None) is not None else None)
 
 
 def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.float64(1)), follow_thresh=np.array([0, 0], dtype=np.float64),
@@ -333,6 +371,7 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     flags = (_lib.FLAG_FULL_OUTPUT if want_rec else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | (_lib.FLAG_FINAL_ROWS if return_final else 0)
     prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
     chunk = None
+    chunk_changed = False
     sink = None
     dev_rows = c.final_rows_device(n) if (isinstance(return_final, str) and return_final == "device") else None
     if record_sink is not None:  # streaming: records leave chunk by chunk; ray_interfaces comes back empty
@@ -351,8 +390,10 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
                 if getattr(e, "code", 0) != -3 or singlechild or attempt == 7:
                     raise
                 chunk = max(256, (chunk if chunk is not None else min(n, 1 << 20)) // 4)
-                c.set_option("nodice_chunk", chunk)
+                c.set_option("nodice_chunk", chunk); chunk_changed = True
     finally:
+        if chunk_changed:
+            c.set_option("nodice_chunk", 1 << 20)   # the smaller passes were for this call only (the context is shared and cached)
         if sink is not None:
             c.L.rt_set_record_sink(c.h, C.cast(None, _lib.RECORD_SINK), None)
         if dev_rows is not None:

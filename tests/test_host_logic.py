@@ -157,3 +157,22 @@ def test_hostsim_arbc_geometry():
     # the oracle driven by the compiled bounds program equals the oracle calling the lambdas
     c = O.trace(sp, rays, sl, 30, [1e-6], 1e-4, -1, True, True, False, compat="matlab", seed=11, program=T.compile_surfaces(sl))
     compare_results(a, c, tol=1e-12)
+
+
+def test_geometry_key_sees_a_changed_closure_and_a_changed_global():
+    """a lambda whose closed-over bound changes keeps its id; the stale bounds program must not be reused"""
+    from raytracer_amd import RayTracer2 as R
+    import cases
+    bound = [5.0]
+    s = cases.Surf(); s.shape = 'sphere'; s.param_list = [np.array([0, 0, 0.]), 10.]; s.n_outside = 1.0; s.n_inside = 1.5; s.surface_type = 'normal'; s.absorption = 0
+    lim = 5.0
+    s.inbounds_function = lambda p: np.reshape(p[:, 2, :] < lim, (p.shape[0], -1))
+    k1 = R._surface_fingerprint(s)
+    lim = 7.0                                            # same function object, same id, new closed-over value
+    k2 = R._surface_fingerprint(s)
+    assert k1 != k2
+    lim = 5.0
+    assert R._surface_fingerprint(s) == k1
+    s.inbounds_function = lambda p: np.reshape(p[:, 2, :] < bound[0], (p.shape[0], -1))
+    k3 = R._surface_fingerprint(s); bound[0] = 6.0
+    assert R._surface_fingerprint(s) != k3

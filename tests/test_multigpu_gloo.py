@@ -10,8 +10,8 @@ import cases
 
 def _oracle_fn(sp, rays, sl, args, kw, base):
     from oracle import oracle as O
-    r = O.trace(sp, rays, sl, *args, ray_id_base=base, **kw)
-    return r.ray_interfaces, r.absorption_table
+    r = O.trace(sp, rays, sl, *args, ray_id_base=base, final=True, **kw)
+    return r.ray_interfaces, r.absorption_table, r.final
 
 
 def _worker(rank, world, port, q):
@@ -22,7 +22,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from raytracer_amd.multigpu import sharded_trace
     sp, rays = cases.isotropic_rays(3001, 5, origin=(3, 0, 0))
-    ris, tab = sharded_trace(sp, rays, cases.sphere_plane(), 10, 1e-9, 1e-6, -1, True, True, False, trace_fn=_oracle_fn, seed=17)
+    ris, tab, fin = sharded_trace(sp, rays, cases.sphere_plane(), 10, 1e-9, 1e-6, -1, True, True, False, trace_fn=_oracle_fn, seed=17, gather_final=True)
+    if rank == 1:
+        q.put(("final@1", fin.numpy().copy()))     # the all-gather leaves the whole table on every rank
     if rank == 0:
         q.put((tab, [r.ray_index for r in ris], [r.intersection_point for r in ris]))
     dist.barrier(); dist.destroy_process_group()
@@ -37,11 +39,13 @@ def test_two_rank_sharding_equals_single_rank():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    tab, idx, pts = q.get(timeout=120)
+    got = [q.get(timeout=120), q.get(timeout=120)]
+    fin1 = next(g[1] for g in got if isinstance(g[0], str)); tab, idx, pts = next(g for g in got if not isinstance(g[0], str))
     for p in procs:
         p.join(60); assert p.exitcode == 0
     sp, rays = cases.isotropic_rays(3001, 5, origin=(3, 0, 0))
-    ref_ris, ref_tab = _oracle_fn(sp, rays, cases.sphere_plane(), (10, 1e-9, 1e-6, -1, True, True, False), dict(seed=17), 0)
+    ref_ris, ref_tab, ref_fin = _oracle_fn(sp, rays, cases.sphere_plane(), (10, 1e-9, 1e-6, -1, True, True, False), dict(seed=17), 0)
+    assert fin1.shape == ref_fin.shape and np.array_equal(fin1, ref_fin, equal_nan=True)   # final rows of all rays, gathered with all_gather_into_tensor
     assert np.allclose(tab, ref_tab, rtol=1e-12, atol=1e-12)          # counter-based RNG: same result for any rank count
     assert len(idx) == len(ref_ris)
     for a, b, c in zip(idx, pts, ref_ris):
