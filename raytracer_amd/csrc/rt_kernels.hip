@@ -810,12 +810,13 @@ struct rt_ctx {
     int64_t upload_chunk = (int64_t)1 << 21;
     bool stream_overlap = true; size_t stream_stage_bytes = (size_t)2 << 30, accumulate_stage_bytes = (size_t)256 << 20;
     double kernel_ms = 0; int n_launches = 0;
+    hipEvent_t evb[3 * 16] = {};                                   // per-step timing events of a batch of level steps (run_trace)
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };    // timing events of run_trace / rt_match_endpoints: created once, so that no error path can leak one
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, seg_per_cu = 8;
+    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, seg_per_cu = 8; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
 };
 
@@ -825,6 +826,7 @@ struct rt_ctx {
 // current), kernels get that pointer as an argument.
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
+constexpr int MAX_BATCH = 16; // level steps launched between two host synchronisations (rt_ctx::evb)
 static unsigned char* g_scratch_ptr[MAX_DEVICES];
 static std::mutex g_scratch_mutex;
 
@@ -846,6 +848,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     ctx->n_cu = pr.multiProcessorCount; ctx->hbm = pr.totalGlobalMem; ctx->name = pr.gcnArchName;
     if (hipMalloc(&ctx->d_counters, 256) != hipSuccess) { g_init_err = "rt_init: hipMalloc failed"; delete ctx; return -1; }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { g_init_err = "rt_init: cannot create events"; rt_free(ctx); return -1; }
+    for (int i = 0; i < 3 * MAX_BATCH; i++) if (hipEventCreate(&ctx->evb[i]) != hipSuccess) { g_init_err = "rt_init: cannot create events"; rt_free(ctx); return -1; }
     if (device < MAX_DEVICES) { // this GPU's copy of `scratch` (each GPU holds its own, at its own address)
         std::lock_guard<std::mutex> lk(g_scratch_mutex);
         if (!g_scratch_ptr[device]) {
@@ -879,6 +882,7 @@ extern "C" void rt_free(rt_ctx* ctx) {
     for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); if (ctx->ev_ready[s]) hipEventDestroy(ctx->ev_ready[s]); if (ctx->ev_copied[s]) hipEventDestroy(ctx->ev_copied[s]); }
     for (int s = 0; s < 2; s++) { if (ctx->in_pin[s]) hipHostFree(ctx->in_pin[s]); if (ctx->ev_up[s]) hipEventDestroy(ctx->ev_up[s]); }
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 3 * MAX_BATCH; i++) if (ctx->evb[i]) hipEventDestroy(ctx->evb[i]);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -916,6 +920,8 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "seg_per_cu") { if (!(value >= 1 && value <= 64)) { ctx->err = "rt_set_option: seg_per_cu must be in 1..64"; return -1; } ctx->seg_per_cu = (int)value; }
     else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
     else if (k == "defer_unified") ctx->defer_unified = value != 0;
+    else if (k == "sync_every") { if (!(value >= 1 && value <= MAX_BATCH)) { ctx->err = "rt_set_option: sync_every must be in 1..16"; return -1; } ctx->sync_every = (int)value; }
+    else if (k == "sync_rays_max") ctx->sync_rays_max = (int64_t)value;
     else if (k == "match_max_level") ctx->match_max_level = std::min(10, std::max(0, (int)value));
     else { ctx->err = "rt_set_option: unknown key " + k; return -1; }
     return 0;
@@ -1252,31 +1258,43 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 a.mode = 1; a.in_d = q[1].d; a.in_i = q[1].i; a.in_m = q[1].m; a.in_stride = q[1].cap;
             }
             int sin = 1; // seg[sin]: counts of the input queue
-            for (; k0 < K && k0 < ctx->level_steps && live > 0 && live >= ctx->level_min_rays; k0++) {
-                a.step = k0; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k0 + 1;
-                a.seg_in = seg[sin]; a.seg_out = seg[sin ^ 1];
-                ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = a.in_stride; ha.n_in = live; ha.seg_in = seg[sin];
-                CK(hipEventRecord(ev0, ctx->stream));
-                ha.split = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->hit_split, (live / nseg + BLOCK - 1) / BLOCK));
-                hipLaunchKernelGGL(khit, dim3((unsigned)(nseg * ha.split)), dim3(BLOCK), lds_hit, ctx->stream, ha);
-                CK(hipEventRecord(ev1, ctx->stream));
-                hipLaunchKernelGGL(kphys, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
-                if (defer) hipLaunchKernelGGL(kphys2, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
-                CK(hipEventRecord(ev2, ctx->stream));
-                CK(hipGetLastError());
+            while (k0 < K && k0 < ctx->level_steps && live > 0 && live >= ctx->level_min_rays) {
+                // The host learns the live count by waiting for the step (the kernels themselves read the counts of their
+                // segments from device memory).  Runs whose steps take milliseconds wait after every step; on smaller ones
+                // the round trip is a tenth to a third of the step (profiles/r2_sweep.json), so `sync_every` steps are
+                // launched back to back on the grid of the first - rays that die only leave tiles without work - and the
+                // counts are read once.  Only where rays cannot multiply (single child) and nothing per step leaves the device.
+                const int batch = (single && !full && live < ctx->sync_rays_max) ? std::max(1, std::min(ctx->sync_every, MAX_BATCH)) : 1;
+                const int nb = (int)std::min<int64_t>(batch, std::min<int64_t>(K, ctx->level_steps) - k0);
+                const int split = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->hit_split, (live / nseg + BLOCK - 1) / BLOCK));
+                for (int j = 0; j < nb; j++) {
+                    const int k = k0 + j;
+                    a.step = k; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k + 1;
+                    a.seg_in = seg[sin]; a.seg_out = seg[sin ^ 1];
+                    ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = a.in_stride; ha.n_in = live; ha.seg_in = seg[sin]; ha.split = split;
+                    CK(hipEventRecord(ctx->evb[3 * j], ctx->stream));
+                    hipLaunchKernelGGL(khit, dim3((unsigned)(nseg * ha.split)), dim3(BLOCK), lds_hit, ctx->stream, ha);
+                    CK(hipEventRecord(ctx->evb[3 * j + 1], ctx->stream));
+                    hipLaunchKernelGGL(kphys, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
+                    if (defer) hipLaunchKernelGGL(kphys2, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
+                    CK(hipEventRecord(ctx->evb[3 * j + 2], ctx->stream));
+                    CK(hipGetLastError());
+                    a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap;
+                    cur ^= 1; sin ^= 1;
+                }
                 unsigned long long nxt = 0, cnt[4];
-                CK(hipMemcpyAsync(&nxt, ctx->d_lvl + k0 + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipMemcpyAsync(&nxt, ctx->d_lvl + k0 + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
                 CK(hipMemcpyAsync(cnt, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
                 CK(hipStreamSynchronize(ctx->stream));
-                float ms = 0;
-                CK(hipEventElapsedTime(&ms, ev0, ev1)); ctx->ms_kind[1] += ms; ctx->n_kind[1]++; ctx->kernel_ms += ms;
-                CK(hipEventElapsedTime(&ms, ev1, ev2)); ctx->ms_kind[2] += ms; ctx->n_kind[2]++; ctx->kernel_ms += ms;
-                ctx->n_launches += defer ? 3 : 2;
+                for (int j = 0; j < nb; j++) {
+                    float ms = 0;
+                    CK(hipEventElapsedTime(&ms, ctx->evb[3 * j], ctx->evb[3 * j + 1])); ctx->ms_kind[1] += ms; ctx->n_kind[1]++; ctx->kernel_ms += ms;
+                    CK(hipEventElapsedTime(&ms, ctx->evb[3 * j + 1], ctx->evb[3 * j + 2])); ctx->ms_kind[2] += ms; ctx->n_kind[2]++; ctx->kernel_ms += ms;
+                }
+                ctx->n_launches += (defer ? 3 : 2) * nb;
                 int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
                 if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace or lower nodice_chunk)" : "rt_trace: ray queue overflow (lower nodice_chunk)"; rc = -3; break; }
-                live = (int64_t)nxt;
-                a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap;
-                cur ^= 1; sin ^= 1;
+                live = (int64_t)nxt; k0 += nb;
             }
             if (rc) break;
             if (go && live > 0 && k0 < K) { // hand-over: the persistent kernel reads a dense queue
