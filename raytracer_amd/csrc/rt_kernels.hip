@@ -518,7 +518,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
     for (int i = threadIdx.x; i < a.S * ROW; i += BLOCK) s_surf[i] = a.surf[i];
     for (int i = threadIdx.x; i < ntab; i += BLOCK) s_tab[i] = 0.0;
     const uint32_t child0 = PASS == 2 ? a.seg_out[blockIdx.x] : 0u;
-    if (threadIdx.x < 6) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred (UNIFIED), dense, deferred (bulk scatters)
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = threadIdx.x == 2 ? child0 : 0u; // live, scattered, children, deferred (UNIFIED), dense, deferred (bulk scatters), next tile (PASS 2)
     __syncthreads();
     PP_ADD(0)
     Geom G{ (udptr)a.surf, (udptr)a.recs, (uuptr)a.smeta, s_surf, a.S, a.lut, a.lut_prec, nullptr, (udptr)a.prog, a.nprog };
@@ -623,7 +623,13 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
             if (at >= 0) store_ray_lean(a.out, at, c);
         }
     } else
-    for (int64_t base = seg0 + (threadIdx.x & ~63); base < n; base += BLOCK) {
+    for (int64_t base = seg0 + (threadIdx.x & ~63);; base += BLOCK) {
+        if constexpr (PASS == 2) { // the rough-surface loop takes a different number of rounds in every wave: tiles are handed out as waves come free
+            uint32_t tile = 0;
+            if (lane_id() == 0) tile = atomicAdd(&s_cnt[6], 1u);
+            base = seg0 + 64 * (int64_t)uni32(tile);
+        }
+        if (base >= n) break;
         int64_t idx = base + lane_id();
         // PASS 2: the wave works together on the rough-surface loop (unified_wave), so all 64 lanes go through the step;
         // those behind the end of the list repeat its last ray and leave no trace
