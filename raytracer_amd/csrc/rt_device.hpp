@@ -49,6 +49,29 @@ RT_HD V3 cross(V3 a, V3 b) {
     return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
 }
 template <class Ptr> RT_HD V3 ld3(Ptr p) { return { p[0], p[1], p[2] }; }
+// 1 / sqrt(x), x > 0 finite: on the device the hardware estimate and two Newton steps (7 instructions, ~1 ulp) instead of
+// an IEEE square root followed by an IEEE division (34) - a physics step normalises half a dozen vectors
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD double rt_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x); const double xh = 0.5 * x;
+    double e = fma(-xh * y, y, 0.5); y = fma(y, e, y);
+    e = fma(-xh * y, y, 0.5); return fma(y, e, y);
+}
+// a / b and sqrt(x) the same way (6 and 10 instructions against 12 and 22).  rt_fdiv: b finite, nonzero and not
+// denormal gives ~1 ulp; anything else gives NaN where IEEE gives 0, inf or a huge number - used only where the divisor
+// is a sum of finite positive terms or where NaN is what the caller tests for.  rt_fsqrt(0) = 0, of a negative number NaN.
+RT_HD double rt_fdiv(double a, double b) { double y = __builtin_amdgcn_rcp(b), e = fma(-b, y, 1.0); y = fma(y, e, y); e = fma(-b, y, 1.0); y = fma(y, e, y); return a * y; }
+RT_HD double rt_fsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x), g = x * y, h = 0.5 * y, r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double e = fma(-g, g, x), v = fma(e, h, g);
+    return x == 0 ? 0.0 : v;
+}
+#else
+RT_HD double rt_rsqrt(double x) { return 1.0 / sqrt(x); }
+RT_HD double rt_fdiv(double a, double b) { return a / b; }
+RT_HD double rt_fsqrt(double x) { return sqrt(x); }
+#endif
 RT_HD V3 normalized_if(V3 a) {
     // no FMA contraction here either: normalising d and -d at two places of the code must give exactly opposite vectors,
     // whatever the compiler makes of the surrounding code (back-reflection: normal = -direction, cross() above)
@@ -56,7 +79,7 @@ RT_HD V3 normalized_if(V3 a) {
 #pragma clang fp contract(off)
 #endif
     const double n = a.x * a.x + a.y * a.y + a.z * a.z;
-    if (n > 0) { const double s = 1.0 / sqrt(n); return { s * a.x, s * a.y, s * a.z }; }
+    if (n > 0) { const double s = rt_rsqrt(n); return { s * a.x, s * a.y, s * a.z }; }
     return a;
 }
 RT_HD int isgn(double x) { return (x > 0) - (x < 0); }
@@ -290,46 +313,60 @@ struct Hit {
 #else
 #define RT_COLD __device__ __noinline__ /* out of line: its cbrt/acos temporaries stay out of the surface loop's registers */
 #endif
+// Division and square root of the solver: hardware estimate + two Newton steps (~1 ulp; 6 and 10 instructions where the
+// IEEE sequences take 12 and 22 - the solver has 20 divisions and 11 roots and runs with a quarter of its lanes on).
+// A quotient whose divisor is zero, denormal or huge comes out NaN or inf instead of IEEE's value: every use below
+// rejects non-finite results already.  The square root of zero is zero (tangent rays live there), of a negative number NaN.
+__device__ __forceinline__ double qs_div(double a, double b) { double y = __builtin_amdgcn_rcp(b), e = fma(-b, y, 1.0); y = fma(y, e, y); e = fma(-b, y, 1.0); y = fma(y, e, y); return a * y; }
+__device__ __forceinline__ double qs_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x), g = x * y, h = 0.5 * y, r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double e = fma(-g, g, x), v = fma(e, h, g);
+    return x == 0 ? 0.0 : v;
+}
 #else
 #define RT_COLD static inline
+static inline double qs_div(double a, double b) { return a / b; }
+static inline double qs_sqrt(double x) { return sqrt(x); }
 #endif
 struct Roots4 { double y0, y1, y2, y3; };
 RT_COLD Roots4 solve_depressed_quartic(double p, double q, double r) {
     double y0, y1, y2, y3;
     // all four slots are always written (NaN = no real root there): static register indices only
     y0 = y1 = y2 = y3 = NAN;
-    double scale = fabs(p) + sqrt(fabs(r)) + 1e-300;
-    if (fabs(q) <= 1e-14 * scale * sqrt(scale)) { // biquadratic
+    double scale = fabs(p) + qs_sqrt(fabs(r)) + 1e-300;
+    if (fabs(q) <= 1e-14 * scale * qs_sqrt(scale)) { // biquadratic
         double disc = p * p - 4 * r;
         if (disc >= 0) {
-            double sq = sqrt(disc), w1 = 0.5 * (-p + sq), w2 = 0.5 * (-p - sq);
-            if (w1 >= 0) { double s = sqrt(w1); y0 = s; y1 = -s; }
-            if (w2 >= 0) { double s = sqrt(w2); y2 = s; y3 = -s; }
+            double sq = qs_sqrt(disc), w1 = 0.5 * (-p + sq), w2 = 0.5 * (-p - sq);
+            if (w1 >= 0) { double s = qs_sqrt(w1); y0 = s; y1 = -s; }
+            if (w2 >= 0) { double s = qs_sqrt(w2); y2 = s; y3 = -s; }
         }
     } else {
         // largest real root z > 0 of z^3 + 2p z^2 + (p^2 - 4r) z - q^2 = 0
-        double A = -p * p / 3.0 - 4 * r, B = -2 * p * p * p / 27.0 + 8 * p * r / 3.0 - q * q;
-        double hB = 0.5 * B, tA = A / 3.0, D = hB * hB + tA * tA * tA, w;
-        if (D > 0) { double sD = sqrt(D); w = cbrt(-hB + sD) + cbrt(-hB - sD); }
-        else { double m = sqrt(-tA), c = -hB / (m * m * m); c = c > 1 ? 1 : (c < -1 ? -1 : c); w = 2 * m * cos(acos(c) / 3.0); }
-        double z = w - 2 * p / 3.0, c1 = 2 * p, c2 = p * p - 4 * r, c3 = -q * q;
+        constexpr double third = 1.0 / 3.0; // constants as factors: what they feed is polished by Newton steps below
+        double A = -p * p * third - 4 * r, B = -2 * p * p * p * (1.0 / 27.0) + 8 * p * r * third - q * q;
+        double hB = 0.5 * B, tA = A * third, D = hB * hB + tA * tA * tA, w;
+        if (D > 0) { double sD = qs_sqrt(D); w = cbrt(-hB + sD) + cbrt(-hB - sD); }
+        else { double m = qs_sqrt(-tA), c = qs_div(-hB, m * m * m); c = c > 1 ? 1 : (c < -1 ? -1 : c); w = 2 * m * cos(acos(c) * third); }
+        double z = w - 2 * p * third, c1 = 2 * p, c2 = p * p - 4 * r, c3 = -q * q;
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             double f = ((z + c1) * z + c2) * z + c3, fp = (3 * z + 2 * c1) * z + c2;
-            if (fp != 0) { double zn = z - f / fp; if (zn > 0 && isfinite(zn)) z = zn; }
+            if (fp != 0) { double zn = z - qs_div(f, fp); if (zn > 0 && isfinite(zn)) z = zn; }
         }
         if (z > 0) {
-            double s = sqrt(z), qs = q / s, t = 0.5 * (p + z - qs), u = 0.5 * (p + z + qs);
+            double s = qs_sqrt(z), qs = qs_div(q, s), t = 0.5 * (p + z - qs), u = 0.5 * (p + z + qs);
             double d1 = z - 4 * t, d2 = z - 4 * u;
-            if (d1 >= 0) { double h = -0.5 * (s + sqrt(d1)); y0 = h; y1 = (h != 0) ? t / h : 0.0; } // y^2 + s y + t
-            if (d2 >= 0) { double h = 0.5 * (s + sqrt(d2)); y2 = h; y3 = (h != 0) ? u / h : 0.0; }  // y^2 - s y + u
+            if (d1 >= 0) { double h = -0.5 * (s + qs_sqrt(d1)); y0 = h; y1 = (h != 0) ? qs_div(t, h) : 0.0; } // y^2 + s y + t
+            if (d2 >= 0) { double h = 0.5 * (s + qs_sqrt(d2)); y2 = h; y3 = (h != 0) ? qs_div(u, h) : 0.0; }  // y^2 - s y + u
         }
     }
 #define RT_POLISH(v)                                                                                 \
     {                                                                                                \
         for (int it = 0; it < 2; it++) {                                                             \
             double f = ((v * v + p) * v + q) * v + r, fp = (4 * v * v + 2 * p) * v + q;              \
-            if (fp != 0) { double vn = v - f / fp; if (isfinite(vn)) v = vn; }                       \
+            if (fp != 0) { double vn = v - qs_div(f, fp); if (isfinite(vn)) v = vn; }                \
         }                                                                                            \
     }
     RT_POLISH(y0) RT_POLISH(y1) RT_POLISH(y2) RT_POLISH(y3)
@@ -1130,10 +1167,11 @@ RT_HD void fresnel_core(const Ray10& in, V3 nrm, double n1, double n2, FresnelCo
     c.cos_i = dot(md, c.n);
     c.goodhit = c.cos_i > 0;
     c.inorm = cross(md, c.n);
-    c.sin_i = sqrt(dot(c.inorm, c.inorm));
+    const double in2 = dot(c.inorm, c.inorm), irs = in2 > 0 ? rt_rsqrt(in2) : 0.0;
+    c.sin_i = in2 * irs;
     c.s0 = in.s0; c.s1 = in.s1; c.s2 = in.s2; c.s3 = in.s3; c.pol = pol;
     if (c.sin_i > 0) {
-        c.inorm = (1.0 / c.sin_i) * c.inorm;
+        c.inorm = irs * c.inorm;
         double c_rot = dot(c.inorm, pol), s_rot = dot(cross(c.inorm, pol), c.d);
         double c2 = c_rot * c_rot - s_rot * s_rot, sn2 = 2 * c_rot * s_rot;
         c.s1 = in.s1 * c2 - in.s2 * sn2; c.s2 = in.s1 * sn2 + in.s2 * c2;
@@ -1144,13 +1182,13 @@ RT_HD void fresnel_core(const Ray10& in, V3 nrm, double n1, double n2, FresnelCo
     c.cos_t = 0;
     if (isinf(n2)) { c.Rs = 1; c.Rp = 1; c.cr = -1; c.ci = 0; c.Ts = 0; c.Tp = 0; c.tst = 0; c.cos_t = 1; }
     else if (arg >= 0) {
-        c.cos_t = sqrt(arg);
+        c.cos_t = rt_fsqrt(arg);
         double a1 = n1 * c.cos_i, a2 = n2 * c.cos_t, b1 = n1 * c.cos_t, b2 = n2 * c.cos_i;
-        double rs = (a1 - a2) / (a1 + a2), rp = -(b1 - b2) / (b1 + b2);
-        c.Rs = rs * rs; c.Rp = rp * rp; c.cr = rs * rp; c.ci = 0; c.Ts = fabs(1 - c.Rs); c.Tp = fabs(1 - c.Rp); c.tst = sqrt(c.Ts * c.Tp);
+        double rs = rt_fdiv(a1 - a2, a1 + a2), rp = -rt_fdiv(b1 - b2, b1 + b2);
+        c.Rs = rs * rs; c.Rp = rp * rp; c.cr = rs * rp; c.ci = 0; c.Ts = fabs(1 - c.Rs); c.Tp = fabs(1 - c.Rp); c.tst = rt_fsqrt(c.Ts * c.Tp);
     } else { // total internal reflection: |rs| = |rp| = 1, only the relative phase matters
-        double kap = sqrt(-arg), A = n1 * c.cos_i, B = n2 * kap, C = n1 * kap, Dd = n2 * c.cos_i;
-        double ia = 1.0 / (A * A + B * B), ic = 1.0 / (Dd * Dd + C * C);
+        double kap = rt_fsqrt(-arg), A = n1 * c.cos_i, B = n2 * kap, C = n1 * kap, Dd = n2 * c.cos_i;
+        double ia = rt_fdiv(1.0, A * A + B * B), ic = rt_fdiv(1.0, Dd * Dd + C * C);
         double rsr = (A * A - B * B) * ia, rsi = -2 * A * B * ia, rpr = (Dd * Dd - C * C) * ic, rpi = -2 * C * Dd * ic;
         c.Rs = 1; c.Rp = 1; c.Ts = 0; c.Tp = 0; c.tst = 0;
         c.cr = rsr * rpr + rsi * rpi; c.ci = rsr * rpi - rsi * rpr; // conj(rs) * rp
@@ -1164,7 +1202,7 @@ RT_HD bool fresnel_yaxis(const FresnelCore& c, V3& ny) {
     ny = cross(c.n, c.inorm);
     double nyn = dot(ny, ny);
     bool goodcut = c.goodhit && nyn > 0;
-    if (goodcut) ny = (1.0 / sqrt(nyn)) * ny;
+    if (goodcut) ny = rt_rsqrt(nyn) * ny;
     return goodcut;
 }
 RT_HD void fresnel_reflected(const FresnelCore& c, Ray10& refl) {
@@ -1221,7 +1259,7 @@ RT_HD V3 facet_normal(Rng& g, V3 indir, V3 sn, V3 sx, V3 sy, double sig, int max
     }
     return f;
 }
-RT_HD void renorm(Ray10& t, double s0) { double f = s0 / t.s0; t.s0 *= f; t.s1 *= f; t.s2 *= f; t.s3 *= f; }
+RT_HD void renorm(Ray10& t, double s0) { double f = rt_fdiv(s0, t.s0); t.s0 *= f; t.s1 *= f; t.s2 *= f; t.s3 *= f; }
 
 // Out of line on the device: the rough-surface loop needs ~170 VGPRs on its own, which must not set the register
 // budget (occupancy) of the whole bounce kernel.  The generator travels by value; the caller re-aligns its stream to
@@ -1236,12 +1274,12 @@ RT_HD UnifiedOut unified_body(Rng g, Ray10 in, V3 nrm, double n1, double n2, dou
     V3 md = -R.d;
     bool scattering = dot(md, N) > 0;
     V3 sx = cross(md, N);
-    double sin_i = sqrt(dot(sx, sx));
-    if (sin_i > 0) sx = (1.0 / sin_i) * sx;
+    const double sx2 = dot(sx, sx), sxr = sx2 > 0 ? rt_rsqrt(sx2) : 0.0, sin_i = sx2 * sxr;
+    if (sin_i > 0) sx = sxr * sx;
     else {
         V3 t = cross(V3{ 1, 0, 0 }, N);
         if (!(dot(t, t) > 0)) t = cross(V3{ 0, 1, 0 }, N);
-        sx = (1.0 / sqrt(dot(t, t))) * t;
+        sx = rt_rsqrt(dot(t, t)) * t;
     }
     V3 sy = cross(N, sx);
     bool insurface = false;
@@ -1269,7 +1307,7 @@ RT_HD UnifiedOut unified_body(Rng g, Ray10 in, V3 nrm, double n1, double n2, dou
                 else {
                     if (roll < c2) nuse = N;
                     else if (roll < c3) nuse = -R.d;
-                    else { V3 od = lambert_dir(g, N, sx, sy); V3 t = od - R.d; nuse = (1.0 / sqrt(dot(t, t))) * t; }
+                    else { V3 od = lambert_dir(g, N, sx, sy); V3 t = od - R.d; nuse = rt_rsqrt(dot(t, t)) * t; }
                     second = true;
                 }
             }
@@ -1280,7 +1318,7 @@ RT_HD UnifiedOut unified_body(Rng g, Ray10 in, V3 nrm, double n1, double n2, dou
             R.s1 = R.s2 = R.s3 = 0; R.s0 *= pdiff;
             V3 t = cross(V3{ 1, 0, 0 }, R.d);
             if (dot(t, t) <= 0) t = cross(V3{ 0, 1, 0 }, R.d);
-            R.pol = (1.0 / sqrt(dot(t, t))) * t;
+            R.pol = rt_rsqrt(dot(t, t)) * t;
         }
     }
     return UnifiedOut{ R, g.idx };
@@ -1400,12 +1438,12 @@ __device__ __forceinline__ UnifiedOut unified_wave(bool need, Rng g, Ray10 in, V
     V3 md = -R.d;
     bool scattering = need && dot(md, N) > 0;
     V3 sx = cross(md, N);
-    double sin_i = sqrt(dot(sx, sx));
-    if (sin_i > 0) sx = (1.0 / sin_i) * sx;
+    const double sx2 = dot(sx, sx), sxr = sx2 > 0 ? rt_rsqrt(sx2) : 0.0, sin_i = sx2 * sxr;
+    if (sin_i > 0) sx = sxr * sx;
     else {
         V3 t = cross(V3{ 1, 0, 0 }, N);
         if (!(dot(t, t) > 0)) t = cross(V3{ 0, 1, 0 }, N);
-        sx = (1.0 / sqrt(dot(t, t))) * t;
+        sx = rt_rsqrt(dot(t, t)) * t;
     }
     V3 sy = cross(N, sx);
     bool insurface = false, crossing = false, second = false;
@@ -1426,7 +1464,7 @@ __device__ __forceinline__ UnifiedOut unified_wave(bool need, Rng g, Ray10 in, V
                         R.s1 = R.s2 = R.s3 = 0; R.s0 *= pdiff;
                         V3 t = cross(V3{ 1, 0, 0 }, R.d);
                         if (dot(t, t) <= 0) t = cross(V3{ 0, 1, 0 }, R.d);
-                        R.pol = (1.0 / sqrt(dot(t, t))) * t;
+                        R.pol = rt_rsqrt(dot(t, t)) * t;
                     }
                 }
                 if (!(scattering && guard++ < maxiter)) { need = false; break; }
@@ -1455,7 +1493,7 @@ __device__ __forceinline__ UnifiedOut unified_wave(bool need, Rng g, Ray10 in, V
                     else {
                         if (roll < c2) nuse = N;
                         else if (roll < c3) nuse = -R.d;
-                        else { V3 od = lambert_dir(g, N, sx, sy); V3 t = od - R.d; nuse = (1.0 / sqrt(dot(t, t))) * t; }
+                        else { V3 od = lambert_dir(g, N, sx, sy); V3 t = od - R.d; nuse = rt_rsqrt(dot(t, t)) * t; }
                         second = true;
                     }
                 }
@@ -1565,10 +1603,10 @@ template <int CF = -1, int UNI = 0> RT_HD void bounce_phys(const Geom& G, const 
         sincos(ph, &sph, &cph);
         V3 xt = cross(sopt, V3{ 1, 0, 0 }), yt = cross(sopt, V3{ 0, 1, 0 });
         if (xt.x == 0 && xt.y == 0 && xt.z == 0) xt = yt;
-        xt = (1.0 / sqrt(dot(xt, xt))) * xt;
+        xt = rt_rsqrt(dot(xt, xt)) * xt;
         yt = cross(sopt, xt);
         V3 od = ct * sopt + (stt * cph) * xt + (stt * sph) * yt - q.r.d;
-        sopt = (1.0 / sqrt(dot(od, od))) * od;
+        sopt = rt_rsqrt(dot(od, od)) * od;
     }
     b.scat = 1; // l_next < inf
     double l_bulk = INFINITY;
@@ -1658,10 +1696,10 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
         sincos(ph, &sph, &cph);
         V3 xt = cross(sopt, V3{ 1, 0, 0 }), yt = cross(sopt, V3{ 0, 1, 0 });
         if (xt.x == 0 && xt.y == 0 && xt.z == 0) xt = yt;
-        xt = (1.0 / sqrt(dot(xt, xt))) * xt;
+        xt = rt_rsqrt(dot(xt, xt)) * xt;
         yt = cross(sopt, xt);
         V3 od = ct * sopt + (stt * cph) * xt + (stt * sph) * yt - q.r.d;
-        sopt = (1.0 / sqrt(dot(od, od))) * od;
+        sopt = rt_rsqrt(dot(od, od)) * od;
     }
     b.scat = 1;
     double l_bulk = INFINITY;
@@ -1696,7 +1734,7 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
         if (tirc) t_s0 = r_s0 * P.tir;
         r_s0 *= f; t_s0 *= f;
         tot = r_s0 + t_s0;
-        const bool roll = rng_uniform(g) < (r_s0 / tot); // :458-462
+        const bool roll = rng_uniform(g) < rt_fdiv(r_s0, tot); // :458-462 (0 / 0: NaN, never smaller)
         // reflected child, or the refracted one where it is a copy of the reflected (tir_handling >= 0)
         const bool as_refl = roll || tirc;
         ch.pol = c.pol;
@@ -1734,7 +1772,7 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
         const bool roll = rng_uniform(g) < (r.s0 / tot);
         if (roll) ch = r;
     }
-    double resc = tot / ch.s0; // :463-466
+    double resc = rt_fdiv(tot, ch.s0); // :463-466
     if (isnan(resc)) resc = 0;
     if (isnan(tot)) tot = 0;
     ch.s0 = tot; ch.s1 *= resc; ch.s2 *= resc; ch.s3 *= resc;
