@@ -63,6 +63,20 @@ def test_tally_only_runs_take_the_lean_step(opts):
     assert abs(t[:, 0:4].sum() + t[-1, 4].sum() - sp.shape[0]) < 1e-6 * sp.shape[0]
 
 
+def test_steps_between_host_syncs_and_segment_count_change_nothing():
+    """run_trace launches up to `sync_every` level steps on the grid of the first before it reads the live count, and picks
+    the number of queue segments by run size: per-ray results do not depend on either (tallies: float atomics, to 1e-9)"""
+    from raytracer_amd import geometries as G
+    sl = G.create_arbc_geometry(G.sbc_full_mc_specs(black_cones=True))      # rays die within ~15 steps: batches run past the last live ray
+    sp, rays = cases.isotropic_rays(40000, 5, origin=(0, 0, 10))
+    args = (40, [1e-6], 1e-4, -1, False, True, False)
+    tabs = [gpu_with(dict(level_min_rays=0, **o), sp, rays.copy(), sl, *args, seed=3, compat="matlab").absorption_table
+            for o in (dict(sync_every=1, seg_per_cu=8), dict(), dict(sync_every=16, seg_per_cu=1), dict(sync_every=3, sync_rays_max=100))]
+    assert tabs[0].any()
+    for t in tabs[1:]:
+        assert t.shape == tabs[0].shape and np.allclose(t, tabs[0], rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("opts", [dict(level_steps=1000, level_min_rays=0), dict(level_steps=0)])
 def test_jar_with_diffuse_reflectors(opts):
     """SURVEY 8d config 5 as worded: 'diffuse' reflector surfaces (MATLAB/RayTracer2.m:394-415) in the jar geometry with
