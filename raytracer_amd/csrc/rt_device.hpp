@@ -330,7 +330,7 @@ static inline double qs_div(double a, double b) { return a / b; }
 static inline double qs_sqrt(double x) { return sqrt(x); }
 #endif
 struct Roots4 { double y0, y1, y2, y3; };
-RT_COLD Roots4 solve_depressed_quartic(double p, double q, double r) {
+RT_HD Roots4 solve_depressed_quartic_body(double p, double q, double r) {
     double y0, y1, y2, y3;
     // all four slots are always written (NaN = no real root there): static register indices only
     y0 = y1 = y2 = y3 = NAN;
@@ -381,6 +381,7 @@ RT_COLD Roots4 solve_depressed_quartic(double p, double q, double r) {
 #undef RT_POLISH
     return Roots4{ y0, y1, y2, y3 };
 }
+RT_COLD Roots4 solve_depressed_quartic(double p, double q, double r) { return solve_depressed_quartic_body(p, q, r); }
 
 // torus normal (unnormalised sign only matters for the orientation): RayToTorus.m:149-158
 template <class Ptr> RT_HD V3 torus_normal(Ptr g, V3 p) {
@@ -660,23 +661,40 @@ template <bool TWO> RT_HD void frame_candidates(const Geom& G, const Prm& P, con
     } else { h.l = c0_ ? l0 : h.l; h.surf = c0_ ? n : h.surf; h.orient = c0_ ? o0 : h.orient; }
 }
 
-// Torus queue of frame members: slot = {p, q, r, t0} in, {l0..l3, sign bits of f'(l)} out (6 doubles per slot).
+// Torus queue of frame members: slot = {p, q, r, t0, window lo, hi} in, {l0..l3 (in the window, ascending; NaN = none), sign bits of f'(l)} out (6 doubles per slot).
 constexpr int TQ_STRIDE = 6;
+// One queued quartic, solved in place by one lane (out of line with the solver: nothing of it competes with the surface
+// loop's registers).
+RT_COLD void frame_torus_slot(double* q) {
+    const double p_ = q[0], q_ = q[1], t0 = q[3];
+    // the owner's window of ray parameters (slab, annulus, min travel, best hit when it queued), a little wider
+    const double wlo = q[4] - 1e-9 * (1 + fabs(q[4])), whi = q[5] + 1e-9 * (1 + fabs(q[5]));
+    Roots4 y = solve_depressed_quartic_body(p_, q_, q[2]);
+    // d.normal at a root has the sign of f'(y) = 4 y^3 + 2 p y + q (times sign(R1 r2), applied by the owner).
+    // Roots outside the window cannot be the owner's hit: they are dropped here, where one lane works per quartic, and
+    // the others sorted to the front (smallest first), so that the owners - all 64 lanes of the wave walking through
+    // every pending torus for the sake of a few - usually have one pair of candidates to test per torus, not two.
+    double l[4] = { y.y0 + t0, y.y1 + t0, y.y2 + t0, y.y3 + t0 }; uint32_t c[4];
+    const double yy[4] = { y.y0, y.y1, y.y2, y.y3 };
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const double f = (4 * yy[m] * yy[m] + 2 * p_) * yy[m] + q_;
+        c[m] = f > 0 ? 1u : (f < 0 ? 2u : 0u);
+        l[m] = ((l[m] >= wlo) & (l[m] <= whi)) ? l[m] : INFINITY; // NaN (no root) fails both
+    }
+#define RT_CE(a_, b_) { const bool sw = l[b_] < l[a_]; const double tl = sw ? l[b_] : l[a_], th = sw ? l[a_] : l[b_]; const uint32_t tc = sw ? c[b_] : c[a_], uc = sw ? c[a_] : c[b_]; l[a_] = tl; l[b_] = th; c[a_] = tc; c[b_] = uc; }
+    RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+    const uint64_t sg = (uint64_t)c[0] | ((uint64_t)c[1] << 2) | ((uint64_t)c[2] << 4) | ((uint64_t)c[3] << 6);
+#pragma unroll
+    for (int m = 0; m < 4; m++) q[m] = l[m] < INFINITY ? l[m] : NAN;
+    double sd; memcpy(&sd, &sg, 8); q[4] = sd;
+}
 RT_HD void frame_torus_flush(const Geom& G, const Prm& P, const FrameQ& F, udptr prog, V3 sp, V3 d, int six_last, bool act, Hit& h, TorusQ& T) {
     if (T.npend == 0) return;
     rt_wave_sync();
     for (int j = rt_lane(); j < T.npend; j += RT_WAVE) { // device: one slot per lane
-        double* q = T.tq + TQ_STRIDE * j;
-        const double p_ = q[0], q_ = q[1], t0 = q[3];
-        Roots4 y = solve_depressed_quartic(p_, q_, q[2]);
-        // d.normal at a root has the sign of f'(y) = 4 y^3 + 2 p y + q (times sign(R1 r2), applied by the owner)
-        uint64_t sg = 0;
-        { double f = (4 * y.y0 * y.y0 + 2 * p_) * y.y0 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)); }
-        { double f = (4 * y.y1 * y.y1 + 2 * p_) * y.y1 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)) << 2; }
-        { double f = (4 * y.y2 * y.y2 + 2 * p_) * y.y2 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)) << 4; }
-        { double f = (4 * y.y3 * y.y3 + 2 * p_) * y.y3 + q_; sg |= (uint64_t)(f > 0 ? 1u : (f < 0 ? 2u : 0u)) << 6; }
-        q[0] = y.y0 + t0; q[1] = y.y1 + t0; q[2] = y.y2 + t0; q[3] = y.y3 + t0;
-        double sd; memcpy(&sd, &sg, 8); q[4] = sd;
+        frame_torus_slot(T.tq + TQ_STRIDE * j);
     }
     rt_wave_sync();
 #pragma unroll 1
@@ -815,7 +833,7 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
                     V3 xs = x + t0 * d;
                     const double X2 = dot(xs, xs), xas = xa0 + t0 * F.da, K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
                     double* q = T.tq + TQ_STRIDE * slot;
-                    q[0] = 2 * K - R4 * F.a; q[1] = 2 * R4 * xas * F.da; q[2] = K * K - R4 * (X2 - xas * xas); q[3] = t0;
+                    q[0] = 2 * K - R4 * F.a; q[1] = 2 * R4 * xas * F.da; q[2] = K * K - R4 * (X2 - xas * xas); q[3] = t0; q[4] = lo; q[5] = hi;
                     T.slotpack |= (uint32_t)(slot + 1) << (8 * T.ntor);
                 }
                 T.torpack |= (unsigned long long)(unsigned)i << (16 * T.ntor);
