@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--host-inputs", action="store_true", help="hand the rays over as host arrays (N x 3, N x 10), as the Python boundary does: "
                     "the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
+    ap.add_argument("--lanes", type=int, default=1, help="2: the library traces the two halves of each batch at the same time on two streams "
+                    "(rt_set_option lanes; +7 %% at 33.5 M rays).  Launches of the two lanes overlap, so per-launch times (roofline) no longer "
+                    "measure a kernel alone: the default stays 1")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,6 +137,8 @@ def main():
     sl, prog, origin, kw = build_workload(a.workload)
     ctx = Context(local)
     ctx.set_program(*prog)
+    if a.lanes != 1:
+        ctx.set_option("lanes", a.lanes)
     S = prog[0].shape[0]
     flags = kw.get("flags", _lib.FLAG_SINGLECHILD)
     cam = None
@@ -240,7 +245,7 @@ def main():
             "config": {"workload": ("%s: %d-surface jar geometry, %s, " + ("MC single-child" if flags & _lib.FLAG_SINGLECHILD else "ray splitting (no dice)") + ", K=%d, thr=%g, %d rays/step/GPU, full_output off")
                                    % (a.workload, S, ("point source" if h_sp is None else "point-source rays handed over as HOST arrays (PCIe-inclusive)") if cam is None
                                       else "camera rays generated on the device", kw["K"], kw["thr"][0], a.rays),
-                       "rays_per_step_per_gpu": a.rays, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
+                       "rays_per_step_per_gpu": a.rays, "lanes": a.lanes, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                               "traffic": traffic, "counter_tflops": counter_tflops, "valu_issue_frac": valu_issue_frac,
@@ -255,6 +260,19 @@ def main():
         }
         if table_sum[0] is not None:
             out["config"]["allreduced_table_sum_last_step"] = table_sum[0]
+        if world == 1 and a.lanes == 1 and cam is None and h_sp is None and (flags & _lib.FLAG_SINGLECHILD) and a.rays >= (1 << 24):
+            # Not the headline value: the same K steps again with the library's `lanes` option at 2 (the two halves of every batch
+            # traced at the same time on two streams; bench.py --lanes 2 makes it the timed configuration).  Its launches overlap,
+            # so the per-launch figures above - taken with one lane - would not describe a kernel alone.
+            ctx.set_option("lanes", 2)
+            step(a.warmup + a.steps)
+            torch.cuda.synchronize(); t1 = time.perf_counter(); inter2 = 0
+            for i in range(a.steps):
+                inter2 += step(a.warmup + a.steps + 1 + i)[0]
+            torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+            ctx.set_option("lanes", 1)
+            out["two_lanes"] = {"value": inter2 / dt2, "unit": "interactions/s", "ms_per_step": 1e3 * dt2 / a.steps, "steps": a.steps,
+                                "note": "same workload, rt_set_option(lanes, 2); measured after the timed region, not part of `value`"}
         if not a.no_cpu_baseline and world == 1 and cam is None:
             out["cpu_baseline"] = cpu_baseline(prog, origin, kw, a.seed)
         print(json.dumps(out))

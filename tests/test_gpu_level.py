@@ -64,17 +64,38 @@ def test_tally_only_runs_take_the_lean_step(opts):
 
 
 def test_steps_between_host_syncs_and_segment_count_change_nothing():
-    """run_trace launches up to `sync_every` level steps on the grid of the first before it reads the live count, and picks
-    the number of queue segments by run size: per-ray results do not depend on either (tallies: float atomics, to 1e-9)"""
+    """run_trace launches up to `sync_every` level steps on the grid of the first before it reads the live count, picks the
+    number of queue segments by run size, and with lanes = 2 traces two halves at once: per-ray results do not depend on
+    any of that (tallies: float atomics, to 1e-9)"""
     from raytracer_amd import geometries as G
     sl = G.create_arbc_geometry(G.sbc_full_mc_specs(black_cones=True))      # rays die within ~15 steps: batches run past the last live ray
     sp, rays = cases.isotropic_rays(40000, 5, origin=(0, 0, 10))
     args = (40, [1e-6], 1e-4, -1, False, True, False)
     tabs = [gpu_with(dict(level_min_rays=0, **o), sp, rays.copy(), sl, *args, seed=3, compat="matlab").absorption_table
-            for o in (dict(sync_every=1, seg_per_cu=8), dict(), dict(sync_every=16, seg_per_cu=1), dict(sync_every=3, sync_rays_max=100))]
+            for o in (dict(sync_every=1, seg_per_cu=8), dict(), dict(sync_every=16, seg_per_cu=1), dict(sync_every=3, sync_rays_max=100),
+                      dict(lanes=2, lanes_min_rays=1000))]   # the two halves traced at the same time on two streams
     assert tabs[0].any()
     for t in tabs[1:]:
         assert t.shape == tabs[0].shape and np.allclose(t, tabs[0], rtol=1e-9, atol=1e-9)
+
+
+def test_two_lanes_write_the_same_device_final_rows():
+    """lanes = 2: the second half of the rays is traced by a second context into the same device buffer of final rows"""
+    from raytracer_amd.RayTracer2 import Context, RayTracer2
+    from raytracer_amd import geometries as G
+    sl = G.create_arbc_geometry(G.sbc_full_mc_specs(black_cones=True))
+    sp, rays = cases.isotropic_rays(30001, 9, origin=(0, 0, 10))
+    got = []
+    for lanes in (1, 2):
+        c = Context(0)
+        try:
+            c.set_option("level_min_rays", 0); c.set_option("lanes", lanes); c.set_option("lanes_min_rays", 1000)
+            out = RayTracer2(sp, rays.copy(), sl, 30, [1e-6], 1e-4, -1, False, True, False, seed=4, compat="matlab", ctx=c, return_final="device")
+            got.append((out[1].copy(), out[3].cpu().numpy().copy()))
+        finally:
+            c.close()
+    assert np.allclose(got[0][0], got[1][0], rtol=1e-9, atol=1e-9) and got[0][0].any()
+    assert np.array_equal(got[0][1], got[1][1], equal_nan=True) and np.any(got[0][1][:, 19] > 0)
 
 
 @pytest.mark.parametrize("opts", [dict(level_steps=1000, level_min_rays=0), dict(level_steps=0)])
