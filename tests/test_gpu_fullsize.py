@@ -114,5 +114,19 @@ def test_config5_full_mc_one_batch():
         (ta, _), (tb, _) = run(n // 2, 0), run(n // 2, n // 2)    # what two GPUs would each do
         rows = max(t.shape[0], ta.shape[0], tb.shape[0])
         assert np.allclose(_pad(ta, rows) + _pad(tb, rows), _pad(t, rows), rtol=1e-9, atol=1e-6)
+        c.set_option("lanes", 2)                                  # the same batch as two halves at the same time on two streams
+        t2, (live2, scat2) = run(n, 0)
+        assert t2.shape == t.shape and np.allclose(t2, t, rtol=1e-9, atol=1e-6) and np.array_equal(live2, live) and np.array_equal(scat2, scat)
+        # ... and from host arrays (the second lane takes the second half of the caller's arrays)
+        m = 1 << 24
+        sp, rays = cases.isotropic_rays(m, 21, origin=origin)
+        prm = c.params(kw["K"], _lib.FLAG_SINGLECHILD, 0, kw["min_travel"], kw["thr"], kw["tir"], 77, 0)
+        P = C.POINTER(C.c_double)
+        tabs = []
+        for lanes in (1, 2):
+            c.set_option("lanes", lanes)
+            c._check(c.L.rt_trace(c.h, sp.ctypes.data_as(P), rays.ctypes.data_as(P), m, C.byref(prm)))
+            tabs.append(c.results(False, False, m)["table"])
+        assert tabs[0].shape == tabs[1].shape and np.allclose(tabs[0], tabs[1], rtol=1e-9, atol=1e-6) and abs(_total(tabs[1]) - m) < 1e-9 * m
     finally:
         c.close()
