@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=1, help="2: the library traces the two halves of each batch at the same time on two streams "
                     "(rt_set_option lanes; +7 %% at 33.5 M rays).  Launches of the two lanes overlap, so per-launch times (roofline) no longer "
                     "measure a kernel alone: the default stays 1")
+    ap.add_argument("--no-two-lanes", action="store_true", help="skip the informational two-lane pass behind the timed region (profiling runs: "
+                    "its launches would be averaged into the per-kernel statistics)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -260,7 +262,7 @@ def main():
         }
         if table_sum[0] is not None:
             out["config"]["allreduced_table_sum_last_step"] = table_sum[0]
-        if world == 1 and a.lanes == 1 and cam is None and h_sp is None and (flags & _lib.FLAG_SINGLECHILD) and a.rays >= (1 << 24):
+        if world == 1 and a.lanes == 1 and not a.no_two_lanes and cam is None and h_sp is None and (flags & _lib.FLAG_SINGLECHILD) and a.rays >= (1 << 24):
             # Not the headline value: the same K steps again with the library's `lanes` option at 2 (the two halves of every batch
             # traced at the same time on two streams; bench.py --lanes 2 makes it the timed configuration).  Its launches overlap,
             # so the per-launch figures above - taken with one lane - would not describe a kernel alone.
