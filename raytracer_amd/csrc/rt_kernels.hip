@@ -76,6 +76,7 @@ struct KArgs {
     int refill_min;         // refill when at least this many lanes of the wave are idle (or all are)
     // level-synchronous path (k_level_hit / k_level_phys)
     int step;                               // the step k both kernels work on
+    uint32_t lean_hash;                     // tally-only single-child runs: the path hash of every ray of that step
     const unsigned long long* cnt_in;       // number of live rays of this step (null: n_in)
     double* hit_l; int32_t* hit_so;         // nearest hit of live ray i: distance, surface * 4 + orientation + 1 (-1: none)
     // segments: block b of a level kernel owns queue slots [b * seg_cap, b * seg_cap + seg_in[b]) and writes the children
@@ -186,14 +187,28 @@ __device__ __forceinline__ void store_ray(const Queue& Q, int64_t idx, const Ray
 
 // tally-only single-child runs (the level kernels' lean step): parent slot and flags mean nothing there (every ray is its own
 // primary and never marked reflected) and the step is a kernel argument, so the queue record is 124 bytes instead of 140
-__device__ __forceinline__ void store_ray_lean(const Queue& Q, int64_t idx, const RayState& c) {
+// The 13 doubles, the ray id as a 32-bit offset from the first ray of the pass, and one word for the two surface indices
+// (six_last is |smix_last| or, after a scatter in the bulk and for initial rays, 0): 112 bytes.  The path hash is not
+// stored: with one child per interaction it is the same for every ray of a step (KArgs::lean_hash).
+__device__ __forceinline__ int32_t lean_pack(int smix, int six) { return (int32_t)((uint32_t)(smix < 0 ? -smix : smix) | (smix < 0 ? 0x80000000u : 0u) | (six == 0 ? 0x40000000u : 0u)); }
+__device__ __forceinline__ int lean_smix(int32_t w) { const int m = (int)((uint32_t)w & 0x3FFFFFFFu); return w < 0 ? -m : m; }
+__device__ __forceinline__ int lean_six(int32_t w) { return ((uint32_t)w & 0x40000000u) ? 0 : (int)((uint32_t)w & 0x3FFFFFFFu); }
+__device__ __forceinline__ void store_ray_lean(const Queue& Q, int64_t idx, const RayState& c, int64_t id_base) {
     double* d = Q.d; const int64_t st = Q.cap;
     d[0 * st + idx] = c.p.x; d[1 * st + idx] = c.p.y; d[2 * st + idx] = c.p.z;
     d[3 * st + idx] = c.r.d.x; d[4 * st + idx] = c.r.d.y; d[5 * st + idx] = c.r.d.z;
     d[6 * st + idx] = c.r.pol.x; d[7 * st + idx] = c.r.pol.y; d[8 * st + idx] = c.r.pol.z;
     d[9 * st + idx] = c.r.s0; d[10 * st + idx] = c.r.s1; d[11 * st + idx] = c.r.s2; d[12 * st + idx] = c.r.s3;
-    Q.i[idx] = c.ray_id;
-    Q.m[idx] = (int32_t)c.hash; Q.m[2 * st + idx] = c.smix_last; Q.m[3 * st + idx] = c.six_last;
+    Q.m[idx] = (int32_t)(c.ray_id - id_base); Q.m[2 * st + idx] = lean_pack(c.smix_last, c.six_last);
+}
+__device__ __forceinline__ void load_queue_ray_lean(const KArgs& a, int64_t idx, RayState& q) {
+    const double* d = a.in_d; const int64_t st = a.in_stride;
+    q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
+    q.r.d = V3{ d[3 * st + idx], d[4 * st + idx], d[5 * st + idx] };
+    q.r.pol = V3{ d[6 * st + idx], d[7 * st + idx], d[8 * st + idx] };
+    q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
+    const int32_t w = a.in_m[2 * st + idx];
+    q.ray_id = a.slot_base + (int64_t)a.in_m[idx]; q.parent = -1; q.hash = a.lean_hash; q.k = a.step; q.smix_last = lean_smix(w); q.six_last = lean_six(w); q.flags = RF_PRIMARY;
 }
 
 // slot allocation for the lanes that are active here: one atomic per wave, consecutive slots in lane order
@@ -431,6 +446,7 @@ struct HitArgs {
     double min_travel; int base, compat;
     double* hit_l; int32_t* hit_so;
     const uint32_t* seg_in; int64_t seg_cap; int split; // split blocks share one segment
+    int lean;                    // the queue holds lean records (store_ray_lean)
 };
 
 // initial rays (host layout as SoA, or generated point source) -> the ray queue both level kernels read
@@ -441,7 +457,7 @@ template <int CF> __global__ void __launch_bounds__(BLOCK) k_level_init(const KA
     RayState q; load_ray(a, idx, q, wantfin);
     q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
     const int64_t sg = idx / a.seg_fill, off = idx % a.seg_fill;
-    store_ray(a.out, sg * a.seg_cap + off, q);
+    if (a.P.flags == FLAG_SINGLE) store_ray_lean(a.out, sg * a.seg_cap + off, q, a.slot_base); else store_ray(a.out, sg * a.seg_cap + off, q);
     if (off == 0) a.seg_out[sg] = (uint32_t)(a.n_in - idx < a.seg_fill ? a.n_in - idx : a.seg_fill);
 }
 // segments -> dense queue (hand-over to the persistent kernel)
@@ -454,8 +470,8 @@ __global__ void __launch_bounds__(BLOCK) k_level_compact(const KArgs a) {
     const int64_t ob = (int64_t)s_base;
     const bool lean = a.P.flags == FLAG_SINGLE; // lean records (store_ray_lean) leave these out
     for (int64_t i = threadIdx.x; i < n; i += BLOCK) {
-        RayState q; load_queue_ray(a, base + i, q);
-        if (lean) { q.k = a.step; q.parent = -1; q.flags = RF_PRIMARY; }
+        RayState q;
+        if (lean) load_queue_ray_lean(a, base + i, q); else load_queue_ray(a, base + i, q);
         store_ray(a.out, ob + i, q);
     }
 }
@@ -484,7 +500,7 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
             const double* q = a.in_d;
             p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
             d = normalized_if(V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] }); // RayToShape.py:11-14
-            six = a.in_m[3 * st + idx];
+            six = a.lean ? lean_six(a.in_m[2 * st + idx]) : a.in_m[3 * st + idx];
         }
         Hit h;
 #ifdef RT_PROFILE
@@ -563,7 +579,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
         // works on next (and the list entry of the one after) is requested before the physics of the current one starts, so
         // the ~2 us an HBM round trip takes under load pass during ~1 500 vector instructions instead of in front of them.
         // (Measured on the unpipelined loop, r2d: its waves spent 55 % of their cycles in s_waitcnt at 3 waves/SIMD.)
-        struct Raw { double v[QD]; double hl; int64_t ray_id; uint32_t hash; int32_t smix_last, six_last, so; };
+        struct Raw { double v[QD]; double hl; int32_t rid, sm, so; };
         const double* D = a.in_d; const int64_t st = a.in_stride; const int lane = lane_id();
         // list entries travel as loaded (no arithmetic on them until the iteration that needs the slot: a use would make the wave wait for the load)
         auto entry_of = [&](int64_t base) -> uint32_t { const int64_t i = base + lane; return (listed && i < n) ? list[i] : 0u; };
@@ -573,7 +589,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
             r.so = a.hit_so[idx]; r.hl = a.hit_l[idx];
 #pragma unroll
             for (int f = 0; f < QD; f++) r.v[f] = D[f * st + idx];
-            r.ray_id = a.in_i[idx]; r.hash = (uint32_t)a.in_m[idx]; r.smix_last = a.in_m[2 * st + idx]; r.six_last = a.in_m[3 * st + idx];
+            r.rid = a.in_m[idx]; r.sm = a.in_m[2 * st + idx];
         };
         const int64_t first = seg0 + (threadIdx.x & ~63);
         int64_t idx1 = slot_of(first, entry_of(first));
@@ -590,7 +606,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
                 RayState q;
                 q.p = V3{ cur.v[0], cur.v[1], cur.v[2] }; q.r.d = normalized_if(V3{ cur.v[3], cur.v[4], cur.v[5] }); q.r.pol = V3{ cur.v[6], cur.v[7], cur.v[8] };
                 q.r.s0 = cur.v[9]; q.r.s1 = cur.v[10]; q.r.s2 = cur.v[11]; q.r.s3 = cur.v[12];
-                q.ray_id = cur.ray_id; q.parent = -1; q.hash = cur.hash; q.k = k; q.smix_last = cur.smix_last; q.six_last = cur.six_last; q.flags = RF_PRIMARY;
+                q.ray_id = a.slot_base + (int64_t)cur.rid; q.parent = -1; q.hash = a.lean_hash; q.k = k; q.smix_last = lean_smix(cur.sm); q.six_last = lean_six(cur.sm); q.flags = RF_PRIMARY;
                 Hit h; h.l = cur.hl; h.surf = cur.so < 0 ? -1 : (cur.so >> 2); h.orient = cur.so < 0 ? 0 : (cur.so & 3) - 1;
                 LeanBounce b;
 #if defined(RT_EXP) && (RT_EXP & 4)
@@ -620,7 +636,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
             PP_ADD(3)
             __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), as an instruction the compiler's own wait-count pass sees (inline asm is opaque to it) */
             PP_ADD(4)
-            if (at >= 0) store_ray_lean(a.out, at, c);
+            if (at >= 0) store_ray_lean(a.out, at, c, a.slot_base);
         }
     } else
     for (int64_t base = seg0 + (threadIdx.x & ~63);; base += BLOCK) {
@@ -643,7 +659,8 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
         if (act || WAVE) {
             if (listed) idx = seg0 + (int64_t)list[idx];
             const int so = a.hit_so[idx];
-            RayState q; load_queue_ray(a, idx, q);
+            RayState q;
+            if constexpr (CF == FLAG_SINGLE) load_queue_ray_lean(a, idx, q); else load_queue_ray(a, idx, q);
             q.k = k;
             q.r.d = normalized_if(q.r.d);
             Hit h; h.l = a.hit_l[idx];
@@ -663,7 +680,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
                     tally_add(t, s_tab, 0, b.fa ? 4 : 3, b.smix_next, b.s0_child);
                     if (k + 1 < P.K && b.fa) {
                         RayState c = lean_child(q, b);
-                        store_ray_lean(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c); // at most one child per ray: the segment cannot overflow
+                        store_ray_lean(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c, a.slot_base); // at most one child per ray: the segment cannot overflow
                     }
                 }
             } else {
@@ -1044,6 +1061,9 @@ int alloc_queue(rt_ctx* ctx, Queue& q, DevBuf& bd, DevBuf& bi, DevBuf& bm, int64
     return 0;
 }
 
+// path hash of every ray of step k when each interaction leaves one child (lean_child(): path_hash(h, k, 0) from h = 0)
+static uint32_t lean_hash_of(int k) { uint32_t h = 0; for (int j = 0; j < k; j++) h = path_hash(h, j, 0); return h; }
+
 // mode 0: h_start/h_rays host arrays or d_soa device SoA; mode 2: point source
 int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm, int64_t soa_stride = 0) {
     if (!ctx->d_surf) { ctx->err = "rt_trace: no surfaces set"; return -1; }
@@ -1212,6 +1232,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     HitArgs ha; memset(&ha, 0, sizeof ha);
     ha.prog = a.prog; ha.nprog = a.nprog; ha.recs = ctx->d_recs; ha.surf = ctx->d_surf; ha.smeta = ctx->d_smeta; ha.S = S;
     ha.min_travel = a.P.min_travel; ha.base = a.P.base; ha.compat = a.P.compat; ha.hit_l = (double*)b_hl.p; ha.hit_so = (int32_t*)b_hso.p;
+    ha.lean = (single && !out) ? 1 : 0;
     const size_t lds_hit = (size_t)TQ_DOUBLES * 8, lds_phys = (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 32;
     if (level) {
         if (lds_phys > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
@@ -1286,7 +1307,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 const int split = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->hit_split, (live / nseg + BLOCK - 1) / BLOCK));
                 for (int j = 0; j < nb; j++) {
                     const int k = k0 + j;
-                    a.step = k; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k + 1;
+                    a.step = k; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k + 1; a.lean_hash = lean_hash_of(k);
                     a.seg_in = seg[sin]; a.seg_out = seg[sin ^ 1];
                     ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = a.in_stride; ha.n_in = live; ha.seg_in = seg[sin]; ha.split = split;
                     CK(hipEventRecord(ctx->evb[3 * j], ctx->stream));
@@ -1315,7 +1336,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             }
             if (rc) break;
             if (go && live > 0 && k0 < K) { // hand-over: the persistent kernel reads a dense queue
-                a.seg_in = seg[sin]; a.out = q[cur]; a.tail = ctx->d_counters + 1; a.step = k0;
+                a.seg_in = seg[sin]; a.out = q[cur]; a.tail = ctx->d_counters + 1; a.step = k0; a.lean_hash = lean_hash_of(k0);
                 hipLaunchKernelGGL(k_level_compact, dim3((unsigned)nseg), dim3(BLOCK), 0, ctx->stream, a);
                 CK(hipGetLastError());
                 CK(hipMemsetAsync(ctx->d_counters + 1, 0, 8, ctx->stream));
@@ -1538,7 +1559,7 @@ extern "C" int rt_trace_device_noalloc(rt_ctx* ctx, const double* d_soa, int64_t
     if (defer) CK(hipFuncSetAttribute((const void*)kphys2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
     HitArgs ha; memset(&ha, 0, sizeof ha);
     ha.prog = a.prog; ha.nprog = a.nprog; ha.recs = ctx->d_recs; ha.surf = ctx->d_surf; ha.smeta = ctx->d_smeta; ha.S = S;
-    ha.min_travel = a.P.min_travel; ha.base = a.P.base; ha.compat = a.P.compat; ha.hit_l = hit_l; ha.hit_so = hit_so;
+    ha.min_travel = a.P.min_travel; ha.base = a.P.base; ha.compat = a.P.compat; ha.hit_l = hit_l; ha.hit_so = hit_so; ha.lean = 1;
     ha.seg_cap = seg_cap; ha.split = (int)((seg_cap + BLOCK - 1) / BLOCK); // one 256-ray tile per block; tiles behind a segment's live count have nothing to do
     a.seg_cap = seg_cap; a.seg_fill = seg_cap;
     uint32_t* sg[2] = { seg, seg + nseg };
@@ -1550,7 +1571,7 @@ extern "C" int rt_trace_device_noalloc(rt_ctx* ctx, const double* d_soa, int64_t
     a.mode = 1; a.in_d = q[1].d; a.in_i = q[1].i; a.in_m = q[1].m; a.in_stride = q_cap;
     int cur = 0, sin = 1;
     for (int k = 0; k < K; k++) {
-        a.step = k; a.n_in = n; a.out = q[cur]; a.tail = lvl + k + 1; a.seg_in = sg[sin]; a.seg_out = sg[sin ^ 1];
+        a.step = k; a.n_in = n; a.out = q[cur]; a.tail = lvl + k + 1; a.seg_in = sg[sin]; a.seg_out = sg[sin ^ 1]; a.lean_hash = lean_hash_of(k);
         ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = q_cap; ha.n_in = n; ha.seg_in = sg[sin];
         hipLaunchKernelGGL(khit, dim3((unsigned)(nseg * ha.split)), dim3(BLOCK), (size_t)TQ_DOUBLES * 8, ctx->stream, ha);
         hipLaunchKernelGGL(kphys, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
