@@ -187,27 +187,50 @@ __device__ __forceinline__ void store_ray(const Queue& Q, int64_t idx, const Ray
 
 // tally-only single-child runs (the level kernels' lean step): parent slot and flags mean nothing there (every ray is its own
 // primary and never marked reflected) and the step is a kernel argument, so the queue record is 124 bytes instead of 140
-// The 13 doubles, the ray id as a 32-bit offset from the first ray of the pass, and one word for the two surface indices
-// (six_last is |smix_last| or, after a scatter in the bulk and for initial rays, 0): 112 bytes.  The path hash is not
+// 11 doubles (below), the ray id as a 32-bit offset from the first ray of the pass, and one word for the two surface
+// indices (bits 0-23 |smix_last|, 31 its sign, 30: six_last is 0 - after a scatter in the bulk and for initial rays - and
+// not |smix_last|) and the two vector codes (bits 24-26, 27-29): 96 bytes.  The path hash is not
 // stored: with one child per interaction it is the same for every ray of a step (KArgs::lean_hash).
 __device__ __forceinline__ int32_t lean_pack(int smix, int six) { return (int32_t)((uint32_t)(smix < 0 ? -smix : smix) | (smix < 0 ? 0x80000000u : 0u) | (six == 0 ? 0x40000000u : 0u)); }
-__device__ __forceinline__ int lean_smix(int32_t w) { const int m = (int)((uint32_t)w & 0x3FFFFFFFu); return w < 0 ? -m : m; }
-__device__ __forceinline__ int lean_six(int32_t w) { return ((uint32_t)w & 0x40000000u) ? 0 : (int)((uint32_t)w & 0x3FFFFFFFu); }
+__device__ __forceinline__ int lean_smix(int32_t w) { const int m = (int)((uint32_t)w & 0xFFFFFFu); return w < 0 ? -m : m; }
+__device__ __forceinline__ int lean_six(int32_t w) { return ((uint32_t)w & 0x40000000u) ? 0 : (int)((uint32_t)w & 0xFFFFFFu); }
+// Direction and polarisation reference are unit vectors: two components travel, the largest one is rebuilt from them
+// (error ~1e-16).  Code: bits 0-1 which component is left out, bit 2 its sign; 3 = the vector is not a unit vector (zero: a
+// polarisation reference along the direction; NaN) and goes as (x, y, 0).
+constexpr int LQD = 11; // doubles of a lean record: p(3) d(2) pol(2) s0..s3
+__device__ __forceinline__ uint32_t uv_pack(V3 v, double& a_, double& b_) {
+    const double ax = fabs(v.x), ay = fabs(v.y), az = fabs(v.z);
+    const uint32_t j = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+    const double n2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const bool unit = fabs(n2 - 1.0) < 1e-6; // (what the kernels hand on is unit to rounding)
+    const double vj = j == 0u ? v.x : (j == 1u ? v.y : v.z);
+    a_ = unit ? (j == 0u ? v.y : (j == 1u ? v.z : v.x)) : v.x;
+    b_ = unit ? (j == 0u ? v.z : (j == 1u ? v.x : v.y)) : v.y;
+    return unit ? (j | (vj < 0 ? 4u : 0u)) : 3u;
+}
+__device__ __forceinline__ V3 uv_unpack(uint32_t code, double a_, double b_) {
+    const uint32_t j = code & 3u;
+    double w = rt_fsqrt(fmax(fma(-a_, a_, fma(-b_, b_, 1.0)), 0.0));
+    w = (code & 4u) ? -w : w;
+    if (j == 3u) return V3{ a_, b_, 0.0 };
+    return j == 0u ? V3{ w, a_, b_ } : (j == 1u ? V3{ b_, w, a_ } : V3{ a_, b_, w });
+}
 __device__ __forceinline__ void store_ray_lean(const Queue& Q, int64_t idx, const RayState& c, int64_t id_base) {
     double* d = Q.d; const int64_t st = Q.cap;
+    double da, db, pa, pb;
+    const uint32_t cd = uv_pack(c.r.d, da, db), cp = uv_pack(c.r.pol, pa, pb);
     d[0 * st + idx] = c.p.x; d[1 * st + idx] = c.p.y; d[2 * st + idx] = c.p.z;
-    d[3 * st + idx] = c.r.d.x; d[4 * st + idx] = c.r.d.y; d[5 * st + idx] = c.r.d.z;
-    d[6 * st + idx] = c.r.pol.x; d[7 * st + idx] = c.r.pol.y; d[8 * st + idx] = c.r.pol.z;
-    d[9 * st + idx] = c.r.s0; d[10 * st + idx] = c.r.s1; d[11 * st + idx] = c.r.s2; d[12 * st + idx] = c.r.s3;
-    Q.m[idx] = (int32_t)(c.ray_id - id_base); Q.m[2 * st + idx] = lean_pack(c.smix_last, c.six_last);
+    d[3 * st + idx] = da; d[4 * st + idx] = db; d[5 * st + idx] = pa; d[6 * st + idx] = pb;
+    d[7 * st + idx] = c.r.s0; d[8 * st + idx] = c.r.s1; d[9 * st + idx] = c.r.s2; d[10 * st + idx] = c.r.s3;
+    Q.m[idx] = (int32_t)(c.ray_id - id_base); Q.m[2 * st + idx] = lean_pack(c.smix_last, c.six_last) | (int32_t)((cd << 24) | (cp << 27));
 }
 __device__ __forceinline__ void load_queue_ray_lean(const KArgs& a, int64_t idx, RayState& q) {
     const double* d = a.in_d; const int64_t st = a.in_stride;
-    q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
-    q.r.d = V3{ d[3 * st + idx], d[4 * st + idx], d[5 * st + idx] };
-    q.r.pol = V3{ d[6 * st + idx], d[7 * st + idx], d[8 * st + idx] };
-    q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
     const int32_t w = a.in_m[2 * st + idx];
+    q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
+    q.r.d = uv_unpack(((uint32_t)w >> 24) & 7u, d[3 * st + idx], d[4 * st + idx]);
+    q.r.pol = uv_unpack(((uint32_t)w >> 27) & 7u, d[5 * st + idx], d[6 * st + idx]);
+    q.r.s0 = d[7 * st + idx]; q.r.s1 = d[8 * st + idx]; q.r.s2 = d[9 * st + idx]; q.r.s3 = d[10 * st + idx];
     q.ray_id = a.slot_base + (int64_t)a.in_m[idx]; q.parent = -1; q.hash = a.lean_hash; q.k = a.step; q.smix_last = lean_smix(w); q.six_last = lean_six(w); q.flags = RF_PRIMARY;
 }
 
@@ -499,8 +522,8 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
         if (act) {
             const double* q = a.in_d;
             p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
-            d = normalized_if(V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] }); // RayToShape.py:11-14
-            six = a.lean ? lean_six(a.in_m[2 * st + idx]) : a.in_m[3 * st + idx];
+            if (a.lean) { const int32_t w = a.in_m[2 * st + idx]; six = lean_six(w); d = normalized_if(uv_unpack(((uint32_t)w >> 24) & 7u, q[3 * st + idx], q[4 * st + idx])); }
+            else { d = normalized_if(V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] }); six = a.in_m[3 * st + idx]; } // RayToShape.py:11-14
         }
         Hit h;
 #ifdef RT_PROFILE
@@ -579,7 +602,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
         // works on next (and the list entry of the one after) is requested before the physics of the current one starts, so
         // the ~2 us an HBM round trip takes under load pass during ~1 500 vector instructions instead of in front of them.
         // (Measured on the unpipelined loop, r2d: its waves spent 55 % of their cycles in s_waitcnt at 3 waves/SIMD.)
-        struct Raw { double v[QD]; double hl; int32_t rid, sm, so; };
+        struct Raw { double v[LQD]; double hl; int32_t rid, sm, so; };
         const double* D = a.in_d; const int64_t st = a.in_stride; const int lane = lane_id();
         // list entries travel as loaded (no arithmetic on them until the iteration that needs the slot: a use would make the wave wait for the load)
         auto entry_of = [&](int64_t base) -> uint32_t { const int64_t i = base + lane; return (listed && i < n) ? list[i] : 0u; };
@@ -588,7 +611,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
             if (idx < 0) return;
             r.so = a.hit_so[idx]; r.hl = a.hit_l[idx];
 #pragma unroll
-            for (int f = 0; f < QD; f++) r.v[f] = D[f * st + idx];
+            for (int f = 0; f < LQD; f++) r.v[f] = D[f * st + idx];
             r.rid = a.in_m[idx]; r.sm = a.in_m[2 * st + idx];
         };
         const int64_t first = seg0 + (threadIdx.x & ~63);
@@ -604,8 +627,9 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
             RayState c; int64_t at = -1;
             if (idx >= 0) {
                 RayState q;
-                q.p = V3{ cur.v[0], cur.v[1], cur.v[2] }; q.r.d = normalized_if(V3{ cur.v[3], cur.v[4], cur.v[5] }); q.r.pol = V3{ cur.v[6], cur.v[7], cur.v[8] };
-                q.r.s0 = cur.v[9]; q.r.s1 = cur.v[10]; q.r.s2 = cur.v[11]; q.r.s3 = cur.v[12];
+                q.p = V3{ cur.v[0], cur.v[1], cur.v[2] };
+                q.r.d = normalized_if(uv_unpack(((uint32_t)cur.sm >> 24) & 7u, cur.v[3], cur.v[4])); q.r.pol = uv_unpack(((uint32_t)cur.sm >> 27) & 7u, cur.v[5], cur.v[6]);
+                q.r.s0 = cur.v[7]; q.r.s1 = cur.v[8]; q.r.s2 = cur.v[9]; q.r.s3 = cur.v[10];
                 q.ray_id = a.slot_base + (int64_t)cur.rid; q.parent = -1; q.hash = a.lean_hash; q.k = k; q.smix_last = lean_smix(cur.sm); q.six_last = lean_six(cur.sm); q.flags = RF_PRIMARY;
                 Hit h; h.l = cur.hl; h.surf = cur.so < 0 ? -1 : (cur.so >> 2); h.orient = cur.so < 0 ? 0 : (cur.so & 3) - 1;
                 LeanBounce b;
