@@ -67,10 +67,32 @@ RT_HD double rt_fsqrt(double x) {
     const double e = fma(-g, g, x), v = fma(e, h, g);
     return x == 0 ? 0.0 : v;
 }
+// sin and cos of an angle of a few turns at most (azimuths 2 pi u, polar angles of facets): two-term reduction by pi/2
+// (exact for |x| < 1e5) and the fdlibm kernels on [-pi/4, pi/4], ~45 instructions for the pair where the library's
+// sincos - which must also serve 1e300 - takes ~200; within an ulp of it on the same argument.
+struct SinCos { double s, c; };
+__device__ __noinline__ SinCos rt_sincos_call(double x) { // out of line: ten polynomial temporaries that the callers' loops need not make room for
+    if (!(fabs(x) < 1e5)) { SinCos r; sincos(x, &r.s, &r.c); return r; }
+    const double n = rint(x * 0.63661977236758134308);
+    const double t = fma(-n, 6.07710050650619224932e-11, fma(-n, 1.57079632673412561417, x));
+    const double z = t * t;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double s = fma(t * z, ps, t);
+    const double hz = 0.5 * z, w = 1.0 - hz, c = w + (((1.0 - w) - hz) + (z * z) * pc);
+    const int q = (int)n & 3;
+    return SinCos{ (q & 1) ? ((q & 2) ? -c : c) : ((q & 2) ? -s : s), (q & 1) ? ((q & 2) ? s : -s) : ((q & 2) ? -c : c) };
+}
+RT_HD void rt_sincos(double x, double* sn, double* cs) { const SinCos r = rt_sincos_call(x); *sn = r.s; *cs = r.c; }
+__device__ __noinline__ double rt_log(double x) { return log(x); } // the library's, out of line for the same reason
+__device__ __noinline__ double rt_exp(double x) { return exp(x); }
 #else
 RT_HD double rt_rsqrt(double x) { return 1.0 / sqrt(x); }
 RT_HD double rt_fdiv(double a, double b) { return a / b; }
 RT_HD double rt_fsqrt(double x) { return sqrt(x); }
+RT_HD void rt_sincos(double x, double* sn, double* cs) { sincos(x, sn, cs); }
+RT_HD double rt_log(double x) { return log(x); }
+RT_HD double rt_exp(double x) { return exp(x); }
 #endif
 RT_HD V3 normalized_if(V3 a) {
     // no FMA contraction here either: normalising d and -d at two places of the code must give exactly opposite vectors,
@@ -136,7 +158,8 @@ RT_HD double rng_uniform(Rng& g) {
 }
 RT_HD double rng_normal(Rng& g) {
     double u1 = rng_uniform(g), u2 = rng_uniform(g);
-    return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2);
+    double s_, c_; rt_sincos(TWO_PI * u2, &s_, &c_);
+    return sqrt(-2.0 * rt_log(1.0 - u1)) * c_;
 }
 RT_HD uint32_t path_hash(uint32_t h, int step, int reflected) {
     h ^= (uint32_t)(2 * step + reflected + 1) * 0x9E3779B9u;
@@ -1265,7 +1288,7 @@ RT_HD void fresnel(const Ray10& in, V3 nrm, double n1, double n2, double tir, Ra
 // chosen normal (spike: mechanical normal, back: -dir, Lambertian: sampled) and ends the crossing.
 RT_HD V3 lambert_dir(Rng& g, V3 sn, V3 sx, V3 sy) { // UnifiedReflectorModel.m:309-316
     double ct = sqrt(rng_uniform(g)), st = sqrt(1 - ct * ct), ph = TWO_PI * rng_uniform(g), sp, cp;
-    sincos(ph, &sp, &cp);
+    rt_sincos(ph, &sp, &cp);
     return ct * sn + (st * cp) * sx + (st * sp) * sy;
 }
 RT_HD V3 facet_normal(Rng& g, V3 indir, V3 sn, V3 sx, V3 sy, double sig, int maxiter) { // .m:278-306
@@ -1273,12 +1296,12 @@ RT_HD V3 facet_normal(Rng& g, V3 indir, V3 sn, V3 sx, V3 sy, double sig, int max
     if (sig == 0) return f;
     for (int it = 0; it < maxiter; it++) {
         double th = fabs(sig * rng_normal(g)), st, ct;
-        sincos(th, &st, &ct);
+        rt_sincos(th, &st, &ct);
         bool out_of_range = th >= 0.5 * 3.14159265358979323846;
         double fmx = sig * 4 < 1 ? sig * 4 : 1;
         bool fail_jac = rng_uniform(g) * fmx > st;
         double ph = TWO_PI * rng_uniform(g), sp, cp;
-        sincos(ph, &sp, &cp);
+        rt_sincos(ph, &sp, &cp);
         f = ct * sn + (st * cp) * sx + (st * sp) * sy;
         bool wrong = dot(indir, f) >= 0;
         if (!(out_of_range || fail_jac || wrong)) break;
@@ -1438,12 +1461,13 @@ __device__ __forceinline__ V3 facet_normal_wave(bool need, Rng& g, V3 indir, V3 
             pending &= ~__ballot(hit);
         }
         // every ray still drawing has a try that the screening let through: the tests themselves, in double precision
-        const double th = fabs(sig * (sqrt(-2.0 * log(1.0 - t_u1)) * cos(TWO_PI * t_u2)));
-        double t_st, t_ct; sincos(th, &t_st, &t_ct);
+        double z_s, z_c; rt_sincos(TWO_PI * t_u2, &z_s, &z_c);
+        const double th = fabs(sig * (sqrt(-2.0 * rt_log(1.0 - t_u1)) * z_c));
+        double t_st, t_ct; rt_sincos(th, &t_st, &t_ct);
         const bool pass1 = t_last || !(th >= 0.5 * 3.14159265358979323846 || t_u3 * fmx_own > t_st);
         const bool mine2 = (want >> lane) & 1ull;
         const double t_u4 = rng_uniform_at(g.c0, g.c1, g.c2, g.step, g.k0, g.k1, idx0 + 4u * (uint32_t)it + 3u);
-        double sp, cp; sincos(TWO_PI * t_u4, &sp, &cp);
+        double sp, cp; rt_sincos(TWO_PI * t_u4, &sp, &cp);
         const V3 cand = t_ct * sn + (t_st * cp) * sx + (t_st * sp) * sy;
         const bool wrong = dot(indir, cand) >= 0;
         if (mine2) { it += 1; if (pass1) f = cand; }                     // that try is behind the ray now, whatever it gave
@@ -1551,7 +1575,7 @@ RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
         phi = ang + a0 + ixf * (a1 - a0);
     }
     double c, s;
-    sincos(phi, &s, &c);
+    rt_sincos(phi, &s, &c);
     double c2 = c * c - s * s, sn2 = 2 * c * s, o1 = r.s1, o2 = r.s2;
     r.s1 = o1 * c2 + o2 * sn2; r.s2 = -o1 * sn2 + o2 * c2;
     V3 oref = r.pol, operp = cross(r.d, r.pol);
@@ -1626,7 +1650,7 @@ template <int CF = -1, int UNI = 0> RT_HD void bounce_phys(const Geom& G, const 
     b.smix_next = b.six_next = (h.surf + P.base) * h.orient; // RayTracer2.py:371
     if (st == ST_DIFFUSE) { // RayTracer2.m:394-415
         double ct = sqrt(rng_uniform(g)), stt = sqrt(1 - ct * ct), ph = rng_uniform(g) * TWO_PI, sph, cph;
-        sincos(ph, &sph, &cph);
+        rt_sincos(ph, &sph, &cph);
         V3 xt = cross(sopt, V3{ 1, 0, 0 }), yt = cross(sopt, V3{ 0, 1, 0 });
         if (xt.x == 0 && xt.y == 0 && xt.z == 0) xt = yt;
         xt = rt_rsqrt(dot(xt, xt)) * xt;
@@ -1636,12 +1660,12 @@ template <int CF = -1, int UNI = 0> RT_HD void bounce_phys(const Geom& G, const 
     }
     b.scat = 1; // l_next < inf
     double l_bulk = INFINITY;
-    if (b.rayl1 < INFINITY) l_bulk = -b.rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
+    if (b.rayl1 < INFINITY) l_bulk = -b.rayl1 * rt_log(rng_uniform(g)); // RayTracer2.py:409
     b.surf_sc = h.l <= l_bulk; b.ray_sc = !b.surf_sc;
     bool uni_sc = UNI != 2 && b.surf_sc && st == ST_UNIFIED, nor_sc = b.surf_sc && !uni_sc;
     if (b.ray_sc) { b.six_next = 0; b.l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
     b.p = pn;
-    double trans = exp(-b.l / b.absl1); // :424-427
+    double trans = rt_exp(-b.l / b.absl1); // :424-427
     b.bulk_abs = b.inc_intensity * (1 - trans);
     b.inc = q.r; b.inc.s0 *= trans; b.inc.s1 *= trans; b.inc.s2 *= trans; b.inc.s3 *= trans;
     b.refr = b.inc; b.refr.s0 = b.refr.s1 = b.refr.s2 = b.refr.s3 = 0; b.refl = b.refr;
@@ -1682,7 +1706,7 @@ RT_HD bool level_ray_scatters(const Geom& G, const Prm& P, int64_t ray_id, uint3
     if (!(rayl1 < INFINITY)) return false;
     Rng g; rng_init(g, P.key0, P.key1, ray_id, hash, k);
     if ((int)row[1] == ST_DIFFUSE) { (void)rng_uniform(g); (void)rng_uniform(g); }
-    const double l_bulk = -rayl1 * log(rng_uniform(g));
+    const double l_bulk = -rayl1 * rt_log(rng_uniform(g));
     return !(h.l <= l_bulk);
 }
 
@@ -1719,7 +1743,7 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
     b.smix_next = b.six_next = (h.surf + P.base) * h.orient; // RayTracer2.py:371
     if (st == ST_DIFFUSE) { // RayTracer2.m:394-415
         double ct = sqrt(rng_uniform(g)), stt = sqrt(1 - ct * ct), ph = rng_uniform(g) * TWO_PI, sph, cph;
-        sincos(ph, &sph, &cph);
+        rt_sincos(ph, &sph, &cph);
         V3 xt = cross(sopt, V3{ 1, 0, 0 }), yt = cross(sopt, V3{ 0, 1, 0 });
         if (xt.x == 0 && xt.y == 0 && xt.z == 0) xt = yt;
         xt = rt_rsqrt(dot(xt, xt)) * xt;
@@ -1729,7 +1753,7 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
     }
     b.scat = 1;
     double l_bulk = INFINITY;
-    if (rayl1 < INFINITY) l_bulk = -rayl1 * log(rng_uniform(g)); // RayTracer2.py:409
+    if (rayl1 < INFINITY) l_bulk = -rayl1 * rt_log(rng_uniform(g)); // RayTracer2.py:409
     const bool surf_sc = (UNI == 2 && NORAY == 1) ? true : (h.l <= l_bulk);
     b.surf_sc = surf_sc;
     if constexpr (UNI == 2 && NORAY == 2) { if (!surf_sc) { b.scat = 2; return; } }
@@ -1737,7 +1761,7 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
     double l = h.l;
     if (!surf_sc) { b.six_next = 0; l = l_bulk; pn = q.p + l_bulk * q.r.d; } // :417-421
     b.p = pn;
-    const double trans = exp(-l / absl1); // :424-427
+    const double trans = rt_exp(-l / absl1); // :424-427
     b.bulk_abs = b.inc_intensity * (1 - trans);
     Ray10 inc = q.r; inc.s0 *= trans; inc.s1 *= trans; inc.s2 *= trans; inc.s3 *= trans;
     const double f = surf_sc ? 1 - row[17] : 1.0; // :447-449
