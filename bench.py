@@ -110,11 +110,11 @@ def main():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--host-inputs", action="store_true", help="hand the rays over as host arrays (N x 3, N x 10), as the Python boundary does: "
                     "the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
-    ap.add_argument("--lanes", type=int, default=1, help="2: the library traces the two halves of each batch at the same time on two streams "
-                    "(rt_set_option lanes; +7 %% at 33.5 M rays).  Launches of the two lanes overlap, so per-launch times (roofline) no longer "
-                    "measure a kernel alone: the default stays 1")
-    ap.add_argument("--no-two-lanes", action="store_true", help="skip the informational two-lane pass behind the timed region (profiling runs: "
-                    "its launches would be averaged into the per-kernel statistics)")
+    ap.add_argument("--lanes", type=int, default=0, help="rt_set_option lanes (0: the library's default, 2): large tally-only runs are traced as two "
+                    "halves at the same time on two streams that take turns with the nearest-hit launch, so one lane's nearest-hit launch (bound by "
+                    "vector issue) runs beside the other's physics launches (memory, latency).  1: one lane, every launch alone on the GPU")
+    ap.add_argument("--no-one-lane", "--no-two-lanes", dest="no_one_lane", action="store_true", help="skip the informational one-lane pass behind the "
+                    "timed region (profiling runs: its launches would be averaged into the per-kernel statistics)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -139,8 +139,9 @@ def main():
     sl, prog, origin, kw = build_workload(a.workload)
     ctx = Context(local)
     ctx.set_program(*prog)
-    if a.lanes != 1:
+    if a.lanes != 0:
         ctx.set_option("lanes", a.lanes)
+    lanes = a.lanes if a.lanes != 0 else 2  # include/rt_mi355x.h: the default
     S = prog[0].shape[0]
     flags = kw.get("flags", _lib.FLAG_SINGLECHILD)
     cam = None
@@ -247,7 +248,7 @@ def main():
             "config": {"workload": ("%s: %d-surface jar geometry, %s, " + ("MC single-child" if flags & _lib.FLAG_SINGLECHILD else "ray splitting (no dice)") + ", K=%d, thr=%g, %d rays/step/GPU, full_output off")
                                    % (a.workload, S, ("point source" if h_sp is None else "point-source rays handed over as HOST arrays (PCIe-inclusive)") if cam is None
                                       else "camera rays generated on the device", kw["K"], kw["thr"][0], a.rays),
-                       "rays_per_step_per_gpu": a.rays, "lanes": a.lanes, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
+                       "rays_per_step_per_gpu": a.rays, "lanes": lanes, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                               "traffic": traffic, "counter_tflops": counter_tflops, "valu_issue_frac": valu_issue_frac,
@@ -255,26 +256,36 @@ def main():
                                       "program exists to skip most of that work, so this is not executed work). counter_tflops = FP64 flops the kernel executed "
                                       "(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2) per second, valu_issue_frac = SQ_ACTIVE_INST_VALU cycles / "
                                       "(GRBM_GUI_ACTIVE x SIMDs), traffic = HBM bytes per launch (TCC_EA0 read/write requests): profiles/counters.json, "
-                                      "null when that file is not from these kernel sources. No dense contraction: MFMA unused"}, **dom),
+                                      "null when that file is not from these kernel sources. No dense contraction: MFMA unused. With lanes = 2 "
+                                      "avg_launch_ms is the event-bracketed time of a launch that shares the GPU with the other lane's physics "
+                                      "launches (that overlap is the point of the lanes); `one_lane` has the same figures for launches that run alone"}, **dom),
             "roofline_path": {"achieved": path, "frac": path / FP64_VALU_PEAK_TFLOPS, "flop_per_interaction": fpi, "kernel_ms_per_step": kms / a.steps,
                               "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
                                             for j, n in enumerate(names)}},
         }
         if table_sum[0] is not None:
             out["config"]["allreduced_table_sum_last_step"] = table_sum[0]
-        if world == 1 and a.lanes == 1 and not a.no_two_lanes and cam is None and h_sp is None and (flags & _lib.FLAG_SINGLECHILD) and a.rays >= (1 << 24):
-            # Not the headline value: the same K steps again with the library's `lanes` option at 2 (the two halves of every batch
-            # traced at the same time on two streams; bench.py --lanes 2 makes it the timed configuration).  Its launches overlap,
-            # so the per-launch figures above - taken with one lane - would not describe a kernel alone.
-            ctx.set_option("lanes", 2)
-            step(a.warmup + a.steps)
-            torch.cuda.synchronize(); t1 = time.perf_counter(); inter2 = 0
-            for i in range(a.steps):
-                inter2 += step(a.warmup + a.steps + 1 + i)[0]
-            torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+        if world == 1 and lanes != 1 and not a.no_one_lane and cam is None and h_sp is None and (flags & _lib.FLAG_SINGLECHILD):
+            # Not the headline value: the same K steps again with one lane, every launch alone on the GPU - the per-kernel times
+            # and the roofline of the dominant kernel without the other lane's launches beside it.
             ctx.set_option("lanes", 1)
-            out["two_lanes"] = {"value": inter2 / dt2, "unit": "interactions/s", "ms_per_step": 1e3 * dt2 / a.steps, "steps": a.steps,
-                                "note": "same workload, rt_set_option(lanes, 2); measured after the timed region, not part of `value`"}
+            step(a.warmup + a.steps)
+            by_kernel[:] = [[0.0, 0], [0.0, 0], [0.0, 0]]; hit_units[0] = 0
+            torch.cuda.synchronize(); t1 = time.perf_counter(); inter1 = 0
+            for i in range(a.steps):
+                inter1 += step(a.warmup + a.steps + 1 + i)[0]
+            torch.cuda.synchronize(); dt1 = time.perf_counter() - t1
+            ctx.set_option("lanes", lanes)
+            h_ms, h_n = by_kernel[1]
+            one = {"value": inter1 / dt1, "unit": "interactions/s", "ms_per_step": 1e3 * dt1 / a.steps, "steps": a.steps,
+                   "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps} for j, n in enumerate(names)},
+                   "note": "same workload, rt_set_option(lanes, 1); measured after the timed region, not part of `value`"}
+            if h_n > 0 and h_ms > 0:
+                ach1 = (hit_units[0] * fph / (h_ms / 1e3)) / 1e12
+                one["roofline"] = {"kernel": "k_level_hit", "launches": h_n, "avg_launch_ms": h_ms / h_n, "units_per_launch": hit_units[0] / h_n,
+                                   "achieved": ach1, "frac": ach1 / FP64_VALU_PEAK_TFLOPS,
+                                   "counter_tflops": (counter_tflops * dom["avg_launch_ms"] / dom["units_per_launch"] * (hit_units[0] / h_n) / (h_ms / h_n)) if counter_tflops is not None else None}
+            out["one_lane"] = one
         if not a.no_cpu_baseline and world == 1 and cam is None:
             out["cpu_baseline"] = cpu_baseline(prog, origin, kw, a.seed)
         print(json.dumps(out))

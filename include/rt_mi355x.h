@@ -188,9 +188,11 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
  * at least that many rays are live, the persistent kernel takes the rest; no cap / 32768), "defer_unified" (0: rays ending
  * on UNIFIED surfaces are not given a physics launch of their own), "hit_split", "seg_per_cu" (queue segments per CU; default
  * 2 for single-child runs up to 16M rays, else 8), "sync_every" / "sync_rays_max" (tally-only single-child runs below that
- * many live rays launch up to that many steps between two host synchronisations; 8 / 16M), "lanes" / "lanes_min_rays" (2:
- * tally-only runs of at least that many rays are traced as two halves at the same time on two streams, by a second context
- * that shares the geometry: +7 % at 33.5M rays; per-kernel timings then overlap; default 1 / 16M), "frames" (0: the
+ * many live rays launch up to that many steps between two host synchronisations; 8 / 16M), "lanes" / "lanes_min_rays" /
+ * "lanes_alternate" (tally-only runs of at least that many rays are traced as that many parts (1..4) at the same time, each on
+ * a stream and host thread of its own by a context that shares the geometry, taking turns with the nearest-hit launch so
+ * that it runs beside the other lane's physics launches: +10 % at 33.5M rays; per-kernel timings (rt_result_timing*) are
+ * then sums over launches that overlap in time; default 2 / 2M / 1), "frames" (0: the
  * reference's formulas for every surface instead of the frame program), "refill_min" (idle lanes per wave that
  * trigger a refill of the persistent kernel, default 4), "blocks_per_cu" (0 = occupancy query), "nodice_chunk" (rays
  * per pass in ray-splitting mode, default 2^20), "lds_budget_kb", "match_max_level" (rt_match_endpoints: deepest level of

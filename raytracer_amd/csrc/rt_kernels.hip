@@ -867,7 +867,10 @@ struct rt_ctx {
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
     // second lane of large tally-only runs (run_trace_lanes): a context of its own that borrows this one's geometry
     // (off by default: the launches of two lanes overlap, which is what it is for, and per-kernel times then mean little)
-    int lanes = 1; int64_t lanes_min_rays = (int64_t)1 << 24; rt_ctx* lane = nullptr; bool is_lane = false, raw_tally = false;
+    int lanes = 2; int64_t lanes_min_rays = (int64_t)1 << 21; rt_ctx* lane[3] = { nullptr, nullptr, nullptr }; bool is_lane = false, raw_tally = false;
+    // the lanes take turns with the nearest-hit launch (run_trace_lanes): what each has recorded so far, and the events
+    struct LanePair { int L; std::atomic<int> rec[4]; std::atomic<int> done[4]; hipEvent_t ev[4][8]; }* pair = nullptr;
+    int pair_id = 0, pair_seq = 0, lanes_alternate = 1;
 };
 
 // ---- rt_trace_device_noalloc: its queues, hits, lists and counters live here instead of in hipMalloc'ed memory.
@@ -916,7 +919,10 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     const char* ls = getenv("RT_LEVEL_STEPS"); if (ls && atoi(ls) >= 0) ctx->level_steps = atoi(ls);
     const char* lm = getenv("RT_LEVEL_MIN_RAYS"); if (lm && atoll(lm) >= 0) ctx->level_min_rays = atoll(lm);
     const char* hs = getenv("RT_HIT_SPLIT"); if (hs && atoi(hs) > 0) ctx->hit_split = atoi(hs);
-    const char* ln = getenv("RT_LANES"); if (ln && atoi(ln) >= 1 && atoi(ln) <= 2) ctx->lanes = atoi(ln);
+    const char* ln = getenv("RT_LANES"); if (ln && atoi(ln) >= 1 && atoi(ln) <= 4) ctx->lanes = atoi(ln);
+    const char* la = getenv("RT_LANES_ALTERNATE"); if (la) ctx->lanes_alternate = atoi(la) != 0;
+    const char* lmr = getenv("RT_LANES_MIN_RAYS"); if (lmr && atoll(lmr) >= 0) ctx->lanes_min_rays = atoll(lmr);
+    const char* sm = getenv("RT_SYNC_RAYS_MAX"); if (sm && atoll(sm) > 0) ctx->sync_rays_max = atoll(sm);
     const char* sc = getenv("RT_SEG_PER_CU"); if (sc && atoi(sc) > 0 && atoi(sc) <= 64) { ctx->seg_per_cu = atoi(sc); ctx->seg_auto = false; }
     const char* hb = getenv("RT_HIT_BLOCKS_PER_CU"); if (hb && atoi(hb) >= 0) ctx->hit_blocks_per_cu = atoi(hb);
     const char* pb = getenv("RT_PHYS_BLOCKS_PER_CU"); if (pb && atoi(pb) >= 0) ctx->phys_blocks_per_cu = atoi(pb);
@@ -927,7 +933,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
 
 extern "C" void rt_free(rt_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->lane) { rt_free(ctx->lane); ctx->lane = nullptr; } // (its geometry pointers are null between calls: they are this context's)
+    for (auto& l : ctx->lane) if (l) { rt_free(l); l = nullptr; } // (their geometry pointers are null between calls: they are this context's)
     hipSetDevice(ctx->device);
     hipFree(ctx->d_surf); hipFree(ctx->d_recs); hipFree(ctx->d_smeta); hipFree(ctx->d_prog); hipFree(ctx->d_cam); hipFree(ctx->d_lut); hipFree(ctx->d_counters); hipFree(ctx->d_table); hipFree(ctx->d_steps); hipFree(ctx->d_lvl);
     for (auto& pb : ctx->pool) hipFree(pb.first);
@@ -956,7 +962,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "nodice_chunk") ctx->nodice_chunk = (int64_t)value;
     else if (k == "lds_budget_kb") ctx->lds_budget = (size_t)(value * 1024);
     else if (k == "release_workspace") {
-        if (ctx->lane) rt_set_option(ctx->lane, "release_workspace", 0);
+        for (rt_ctx* l : ctx->lane) if (l) rt_set_option(l, "release_workspace", 0);
         hipSetDevice(ctx->device); for (auto& pb : ctx->pool) hipFree(pb.first); ctx->pool.clear();
         for (int s = 0; s < 2; s++) { if (ctx->pin[s]) hipHostFree(ctx->pin[s]); ctx->pin[s] = nullptr; ctx->pin_bytes[s] = 0; }
         for (int s = 0; s < 2; s++) { if (ctx->in_pin[s]) hipHostFree(ctx->in_pin[s]); ctx->in_pin[s] = nullptr; ctx->in_pin_bytes[s] = 0; }
@@ -973,8 +979,9 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "seg_per_cu") { if (!(value >= 1 && value <= 64)) { ctx->err = "rt_set_option: seg_per_cu must be in 1..64"; return -1; } ctx->seg_per_cu = (int)value; ctx->seg_auto = false; }
     else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
     else if (k == "defer_unified") ctx->defer_unified = value != 0;
-    else if (k == "lanes") { if (!(value >= 1 && value <= 2)) { ctx->err = "rt_set_option: lanes must be 1 or 2"; return -1; } ctx->lanes = (int)value; }
+    else if (k == "lanes") { if (!(value >= 1 && value <= 4)) { ctx->err = "rt_set_option: lanes must be 1 to 4"; return -1; } ctx->lanes = (int)value; }
     else if (k == "lanes_min_rays") ctx->lanes_min_rays = (int64_t)value;
+    else if (k == "lanes_alternate") ctx->lanes_alternate = value != 0;
     else if (k == "sync_every") { if (!(value >= 1 && value <= MAX_BATCH)) { ctx->err = "rt_set_option: sync_every must be in 1..16"; return -1; } ctx->sync_every = (int)value; }
     else if (k == "sync_rays_max") ctx->sync_rays_max = (int64_t)value;
     else if (k == "match_max_level") ctx->match_max_level = std::min(10, std::max(0, (int)value));
@@ -1334,9 +1341,17 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                     a.step = k; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k + 1; a.lean_hash = lean_hash_of(k);
                     a.seg_in = seg[sin]; a.seg_out = seg[sin ^ 1];
                     ha.in_d = a.in_d; ha.in_m = a.in_m; ha.in_stride = a.in_stride; ha.n_in = live; ha.seg_in = seg[sin]; ha.split = split;
+                    if (ctx->pair) { // round robin: lane m's i-th nearest-hit launch starts when lane m-1's i-th has ended, lane 0's when the last lane's (i-1)-th has
+                        const int me = ctx->pair_id, ot = me == 0 ? ctx->pair->L - 1 : me - 1, need = ctx->pair_seq - (me == 0 ? 1 : 0);
+                        if (need >= 0) {
+                            while (ctx->pair->rec[ot].load(std::memory_order_acquire) <= need && !ctx->pair->done[ot].load(std::memory_order_acquire)) std::this_thread::yield();
+                            if (ctx->pair->rec[ot].load(std::memory_order_acquire) > need) CK(hipStreamWaitEvent(ctx->stream, ctx->pair->ev[ot][need & 7], 0));
+                        }
+                    }
                     CK(hipEventRecord(ctx->evb[3 * j], ctx->stream));
                     hipLaunchKernelGGL(khit, dim3((unsigned)(nseg * ha.split)), dim3(BLOCK), lds_hit, ctx->stream, ha);
                     CK(hipEventRecord(ctx->evb[3 * j + 1], ctx->stream));
+                    if (ctx->pair) { CK(hipEventRecord(ctx->pair->ev[ctx->pair_id][ctx->pair_seq & 7], ctx->stream)); ctx->pair_seq++; ctx->pair->rec[ctx->pair_id].store(ctx->pair_seq, std::memory_order_release); }
                     hipLaunchKernelGGL(kphys, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
                     if (defer) hipLaunchKernelGGL(kphys2, dim3((unsigned)nseg), dim3(BLOCK), lds_phys, ctx->stream, a);
                     CK(hipEventRecord(ctx->evb[3 * j + 2], ctx->stream));
@@ -1455,55 +1470,84 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     return 0;
 }
 
-// Two lanes.  The launches of a step leave the machine partly idle at their ends (the last blocks of a launch run while
-// the other CUs wait for the next one), and the physics launches are latency-bound: two independent halves of the rays,
-// traced at the same time on two streams by two host threads, fill each other's gaps - +7 % at 33.5 M rays
-// (5.08e9 -> 5.43e9 interactions/s), nothing below ~16 M (each half then runs on the steep part of the size curve).
-// The second lane is a context of its own (stream, queues, counters, workspace) that shares the geometry; rays never
-// interact and are keyed by ray id, so the split changes no result.  Tally-only and device-final-row runs only.
+// Lanes.  The nearest-hit launch is bound by vector issue (0.72 of all cycles, no memory traffic to speak of), the physics
+// launches by HBM traffic and the latency of FP64 dependency chains (half the issue slots idle): run beside each other
+// they fill each other's gaps.  So a large tally-only run is traced as `lanes` (2) independent parts at the same time,
+// each by a context of its own (stream, queues, counters, workspace; the geometry is shared) on a host thread of its own,
+// and the lanes take turns with the nearest-hit launch - lane m's i-th starts when lane m-1's i-th has ended (events
+// across the streams) - so that it runs beside the other lane's physics and not beside its twin: 33.5 M rays
+// 5.58e9 -> 6.15e9 interactions/s (left to chance, without the turns: 5.90e9); +9 % down to 2 M rays.  Three and four
+// lanes are slower than two (each launch then shares the registers of a SIMD with two others).  Rays never interact and
+// are keyed by ray id, so the split changes no result.  Tally-only and device-final-row runs only.
 static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm) {
     const bool full = prm->flags & RT_FLAG_FULL_OUTPUT, single = prm->flags & RT_FLAG_SINGLECHILD, wantfin = prm->flags & RT_FLAG_FINAL_ROWS;
     const bool eligible = ctx->lanes >= 2 && !ctx->is_lane && (mode == 0 || mode == 2) && single && !full && !(prm->follow_threshold[1] < 0) && (!wantfin || ctx->d_fin_user) &&
                           ctx->level_steps > 0 && n >= ctx->lanes_min_rays && !ctx->sink && ctx->d_surf && prm->max_scatters >= 1 && prm->max_scatters <= 4094;
     if (!eligible) return run_trace(ctx, mode, h_start, h_rays, d_soa, origin, n, prm);
-    if (!ctx->lane) {
-        rt_ctx* l = nullptr;
-        if (rt_init(ctx->device, &l) != 0) { ctx->err = "rt_trace: cannot create the second lane: " + g_init_err; return -1; }
-        l->is_lane = true; ctx->lane = l;
+    const int L = std::min(ctx->lanes, 4);
+    rt_ctx* lc[4] = { ctx, nullptr, nullptr, nullptr };
+    for (int j = 1; j < L; j++) {
+        if (!ctx->lane[j - 1]) {
+            rt_ctx* l = nullptr;
+            if (rt_init(ctx->device, &l) != 0) { ctx->err = "rt_trace: cannot create another lane: " + g_init_err; return -1; }
+            l->is_lane = true; ctx->lane[j - 1] = l;
+        }
+        rt_ctx* l = lc[j] = ctx->lane[j - 1];
+        // the lane sees the parent's geometry and options as they are now
+        l->d_surf = ctx->d_surf; l->d_recs = ctx->d_recs; l->d_smeta = ctx->d_smeta; l->d_prog = ctx->d_prog; l->d_lut = ctx->d_lut; l->d_cam = ctx->d_cam;
+        l->nprog_frames = ctx->nprog_frames; l->nprog_generic = ctx->nprog_generic; l->use_frames = ctx->use_frames; l->frames_have_generic = ctx->frames_have_generic;
+        l->has_rayleigh = ctx->has_rayleigh; l->has_unified = ctx->has_unified; l->defer_unified = ctx->defer_unified; l->S = ctx->S; l->lut_n = ctx->lut_n;
+        l->nodice_chunk = ctx->nodice_chunk; l->refill_min = ctx->refill_min; l->blocks_per_cu = ctx->blocks_per_cu; l->lds_budget = ctx->lds_budget;
+        l->level_steps = ctx->level_steps; l->level_min_rays = ctx->level_min_rays; l->hit_blocks_per_cu = ctx->hit_blocks_per_cu; l->phys_blocks_per_cu = ctx->phys_blocks_per_cu;
+        l->hit_split = ctx->hit_split; l->seg_per_cu = ctx->seg_per_cu; l->seg_auto = ctx->seg_auto; l->sync_every = ctx->sync_every; l->sync_rays_max = ctx->sync_rays_max;
+        l->upload_chunk = ctx->upload_chunk; l->stream_overlap = ctx->stream_overlap;
     }
-    rt_ctx* l = ctx->lane;
-    // the lane sees the parent's geometry and options as they are now
-    l->d_surf = ctx->d_surf; l->d_recs = ctx->d_recs; l->d_smeta = ctx->d_smeta; l->d_prog = ctx->d_prog; l->d_lut = ctx->d_lut; l->d_cam = ctx->d_cam;
-    l->nprog_frames = ctx->nprog_frames; l->nprog_generic = ctx->nprog_generic; l->use_frames = ctx->use_frames; l->frames_have_generic = ctx->frames_have_generic;
-    l->has_rayleigh = ctx->has_rayleigh; l->has_unified = ctx->has_unified; l->defer_unified = ctx->defer_unified; l->S = ctx->S; l->lut_n = ctx->lut_n;
-    l->nodice_chunk = ctx->nodice_chunk; l->refill_min = ctx->refill_min; l->blocks_per_cu = ctx->blocks_per_cu; l->lds_budget = ctx->lds_budget;
-    l->level_steps = ctx->level_steps; l->level_min_rays = ctx->level_min_rays; l->hit_blocks_per_cu = ctx->hit_blocks_per_cu; l->phys_blocks_per_cu = ctx->phys_blocks_per_cu;
-    l->hit_split = ctx->hit_split; l->seg_per_cu = ctx->seg_per_cu; l->seg_auto = ctx->seg_auto; l->sync_every = ctx->sync_every; l->sync_rays_max = ctx->sync_rays_max;
-    l->upload_chunk = ctx->upload_chunk; l->stream_overlap = ctx->stream_overlap;
-    const size_t W = ctx->workspace_bytes; ctx->workspace_bytes = W / 2; l->workspace_bytes = W / 2;
-    const int64_t nA = (n / 2 + 255) & ~(int64_t)255, nB = n - nA;
-    rt_params pB = *prm; pB.ray_id_base += nA;
+    const size_t W = ctx->workspace_bytes;
+    const int64_t per = ((n + L - 1) / L + 255) & ~(int64_t)255; // rays of a lane (the last one takes what is left: n >= lanes_min_rays, so it is not empty)
     double* fin_user = ctx->d_fin_user; const int64_t fin_rows = ctx->fin_user_rows;
-    if (fin_user) { l->d_fin_user = fin_user + (size_t)nA * FIN; l->fin_user_rows = fin_rows - nA; } else { l->d_fin_user = nullptr; l->fin_user_rows = 0; }
-    ctx->raw_tally = true; l->raw_tally = true;
-    int rcB = 0;
-    std::thread tB([&] {
-        rcB = run_trace(l, mode, h_start ? h_start + 3 * nA : nullptr, h_rays ? h_rays + 10 * nA : nullptr, d_soa ? d_soa + nA : nullptr, origin, nB, &pB, d_soa ? n : 0);
-    });
-    const int rcA = run_trace(ctx, mode, h_start, h_rays, d_soa, origin, nA, prm, d_soa ? n : 0);
-    tB.join();
-    ctx->raw_tally = false; l->raw_tally = false; ctx->workspace_bytes = W;
-    l->d_surf = l->d_recs = l->d_prog = l->d_lut = l->d_cam = nullptr; l->d_smeta = nullptr; l->d_fin_user = nullptr; // not the lane's to free
-    if (rcA) return rcA;
-    if (rcB) { ctx->err = l->err; return rcB; }
+    rt_params pl[4]; int64_t first[4], cnt[4]; int rcs[4] = { 0, 0, 0, 0 };
+    for (int j = 0; j < L; j++) {
+        first[j] = per * j; cnt[j] = std::max<int64_t>(0, std::min<int64_t>(per, n - first[j]));
+        pl[j] = *prm; pl[j].ray_id_base += first[j];
+        lc[j]->workspace_bytes = W / L; lc[j]->raw_tally = true;
+        if (j > 0) { if (fin_user) { lc[j]->d_fin_user = fin_user + (size_t)first[j] * FIN; lc[j]->fin_user_rows = fin_rows - first[j]; } else { lc[j]->d_fin_user = nullptr; lc[j]->fin_user_rows = 0; } }
+    }
+    // The nearest-hit launch is bound by vector issue, the physics launches by memory and dependency latency: the lanes
+    // take turns with the former (events across the streams, round robin), so that one lane's nearest-hit launch runs
+    // beside the others' physics and not beside its twin.
+    rt_ctx::LanePair pair; bool paired = false; pair.L = L;
+    for (int i = 0; i < 4; i++) { pair.rec[i].store(0); pair.done[i].store(0); }
+    if (ctx->lanes_alternate) {
+        paired = true;
+        for (int i = 0; i < 8 * L && paired; i++) if (hipEventCreateWithFlags(&pair.ev[i / 8][i % 8], hipEventDisableTiming) != hipSuccess) { for (int j = 0; j < i; j++) hipEventDestroy(pair.ev[j / 8][j % 8]); paired = false; }
+    }
+    if (paired) for (int j = 0; j < L; j++) { lc[j]->pair = &pair; lc[j]->pair_id = j; lc[j]->pair_seq = 0; }
+    auto run_lane = [&](int j) {
+        if (cnt[j] > 0) rcs[j] = run_trace(lc[j], mode, h_start ? h_start + 3 * first[j] : nullptr, h_rays ? h_rays + 10 * first[j] : nullptr, d_soa ? d_soa + first[j] : nullptr, origin, cnt[j], &pl[j], d_soa ? n : 0);
+        pair.done[j].store(1, std::memory_order_release);
+    };
+    std::vector<std::thread> th;
+    for (int j = 1; j < L; j++) th.emplace_back(run_lane, j);
+    run_lane(0);
+    for (auto& t : th) t.join();
+    if (paired) for (int i = 0; i < 8 * L; i++) hipEventDestroy(pair.ev[i / 8][i % 8]);
+    ctx->workspace_bytes = W;
+    for (int j = 0; j < L; j++) { lc[j]->pair = nullptr; lc[j]->raw_tally = false; }
+    for (int j = 1; j < L; j++) { rt_ctx* l = lc[j]; l->d_surf = l->d_recs = l->d_prog = l->d_lut = l->d_cam = nullptr; l->d_smeta = nullptr; l->d_fin_user = nullptr; } // not the lanes' to free
+    if (rcs[0]) return rcs[0];
+    for (int j = 1; j < L; j++) if (rcs[j]) { ctx->err = lc[j]->err; return rcs[j]; }
     const int K = prm->max_scatters, S = ctx->S; const size_t row = (size_t)5 * S * 2;
-    for (size_t i = 0; i < ctx->table.size() && i < l->table.size(); i++) ctx->table[i] += l->table[i];
+    for (int j = 1; j < L; j++) {
+        rt_ctx* l = lc[j]; if (cnt[j] <= 0) continue;
+        for (size_t i = 0; i < ctx->table.size() && i < l->table.size(); i++) ctx->table[i] += l->table[i];
+        for (int k = 0; k < K; k++) { ctx->n_live[k] += l->n_live[k]; ctx->n_scat[k] += l->n_scat[k]; }
+        ctx->kernel_ms += l->kernel_ms; ctx->n_launches += l->n_launches; // sums over the lanes: they overlap in time
+        for (int i = 0; i < 3; i++) { ctx->ms_kind[i] += l->ms_kind[i]; ctx->n_kind[i] += l->n_kind[i]; }
+    }
     int ns = 0;
-    for (int k = 0; k < K; k++) { ctx->n_live[k] += l->n_live[k]; ctx->n_scat[k] += l->n_scat[k]; if (ctx->n_live[k] > 0) ns = k + 1; }
+    for (int k = 0; k < K; k++) if (ctx->n_live[k] > 0) ns = k + 1;
     for (int k = 0; k < ns; k++) if (ctx->n_scat[k] == 0) std::fill(ctx->table.begin() + (size_t)k * row, ctx->table.begin() + (size_t)(k + 1) * row, 0.0); // RayTracer2.py:405-407 on the whole
     ctx->num_steps = ns; ctx->n_rays = n;
-    ctx->kernel_ms += l->kernel_ms; ctx->n_launches += l->n_launches; // sums over both lanes: they overlap in time
-    for (int i = 0; i < 3; i++) { ctx->ms_kind[i] += l->ms_kind[i]; ctx->n_kind[i] += l->n_kind[i]; }
     return 0;
 }
 

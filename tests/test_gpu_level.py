@@ -73,7 +73,8 @@ def test_steps_between_host_syncs_and_segment_count_change_nothing():
     args = (40, [1e-6], 1e-4, -1, False, True, False)
     tabs = [gpu_with(dict(level_min_rays=0, **o), sp, rays.copy(), sl, *args, seed=3, compat="matlab").absorption_table
             for o in (dict(sync_every=1, seg_per_cu=8), dict(), dict(sync_every=16, seg_per_cu=1), dict(sync_every=3, sync_rays_max=100),
-                      dict(lanes=2, lanes_min_rays=1000))]   # the two halves traced at the same time on two streams
+                      dict(lanes=2, lanes_min_rays=1000),    # the two halves traced at the same time on two streams, taking turns with the nearest-hit launch
+                      dict(lanes=3, lanes_min_rays=1000, sync_every=1), dict(lanes=4, lanes_min_rays=1000, lanes_alternate=0))]
     assert tabs[0].any()
     for t in tabs[1:]:
         assert t.shape == tabs[0].shape and np.allclose(t, tabs[0], rtol=1e-9, atol=1e-9)
