@@ -646,8 +646,17 @@ enum { FA_AXIAL = 0, FA_RADIAL2 = 1, FA_DIST2 = 2 };
 //   PK_FRAME c0(3) a^(3) | PK_PLANE ka, sigma | PK_CYL r, r^2 | PK_SPHERE t, r, t^2 - r^2 | PK_QUAD alpha, gamma, pa, R'
 //   PK_TORUS t, R1, r2, centre(3)
 struct FrameQ { double xa, da, ida, a, ia, hb, uu, xd, xx; int sda; };
-struct PRec { double w[PREC]; };
-template <class Ptr> RT_HD PRec prec_load(Ptr r) { PRec p; for (int j = 0; j < PREC; j++) p.w[j] = r[j]; return p; }
+// Only the meta word is read when the record is, the others where the kind's code uses them (scalar loads of just those
+// words): a record held in full is 32 scalar registers, and the surface loop then spills ~175 of them - as vector-lane
+// writes, which take issue slots of the unit the kernel is bound by.  Measured (nearest hit, ms/step): all 16 words up
+// front 242.6, 10 words 236.6, 7 words 249.4, 4 words 237.6, the meta word alone 231.4 (41 spilled).
+#ifndef RT_PREC_EAGER
+#define RT_PREC_EAGER 1
+#endif
+constexpr int PREC_EAGER = RT_PREC_EAGER;
+struct PRec { double w[PREC_EAGER]; udptr p; };
+RT_HD double prec_w(const PRec& R, int j) { return j < PREC_EAGER ? R.w[j] : R.p[j]; }
+RT_HD PRec prec_load(udptr r) { PRec p; for (int j = 0; j < PREC_EAGER; j++) p.w[j] = r[j]; p.p = r; return p; }
 
 RT_HD double frame_coord(const FrameQ& F, uint32_t coord, double t, double l) {
     if (coord == FA_AXIAL) return F.xa + l * F.da;
@@ -668,9 +677,9 @@ template <bool TWO> RT_HD void frame_candidates(const Geom& G, const Prm& P, con
     const bool first = n < h.surf;
     bool c0_ = act & ok0 & wins_nb(l0, lmin, h.l, first), c1_ = TWO ? (act & ok1 & wins_nb(l1, lmin, h.l, first)) : false;
     const uint32_t na = (mlo >> 16) & 3u;
-    if (na > 0) { const uint32_t ck = (mlo >> 20) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, R.w[9], l0), R.w[7], R.w[8]); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, R.w[9], l1), R.w[7], R.w[8]); }
-    if (na > 1) { const uint32_t ck = (mlo >> 24) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, R.w[12], l0), R.w[10], R.w[11]); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, R.w[12], l1), R.w[10], R.w[11]); }
-    if (na > 2) { const uint32_t ck = (mlo >> 28) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, R.w[15], l0), R.w[13], R.w[14]); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, R.w[15], l1), R.w[13], R.w[14]); }
+    if (na > 0) { const uint32_t ck = (mlo >> 20) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, prec_w(R, 9), l0), prec_w(R, 7), prec_w(R, 8)); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, prec_w(R, 9), l1), prec_w(R, 7), prec_w(R, 8)); }
+    if (na > 1) { const uint32_t ck = (mlo >> 24) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, prec_w(R, 12), l0), prec_w(R, 10), prec_w(R, 11)); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, prec_w(R, 12), l1), prec_w(R, 10), prec_w(R, 11)); }
+    if (na > 2) { const uint32_t ck = (mlo >> 28) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, prec_w(R, 15), l0), prec_w(R, 13), prec_w(R, 14)); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, prec_w(R, 15), l1), prec_w(R, 13), prec_w(R, 14)); }
     const int blen = (int)(mhi >> 20);
     if (blen != 0) { // residual bounds program, at the point
         const int boff = (int)(mhi & 0xFFFFFu);
@@ -729,7 +738,7 @@ RT_HD void frame_torus_flush(const Geom& G, const Prm& P, const FrameQ& F, udptr
         const uint32_t mlo = (uint32_t)meta, mhi = (uint32_t)(meta >> 32);
         const double* q = T.tq + TQ_STRIDE * (my ? my - 1 : 0);
         uint64_t sg; { double sd = q[4]; memcpy(&sg, &sd, 8); }
-        const int flip = (R.w[2] * R.w[3] < 0) ? -1 : 1;
+        const int flip = (prec_w(R, 2) * prec_w(R, 3) < 0) ? -1 : 1;
         const bool mine = act & (my != 0);
         // roots in pairs; a NaN root fails every comparison
 #pragma unroll 1
@@ -763,17 +772,17 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
         const uint32_t kind = mlo & 15u;
         if (kind == PK_FRAME) {
             frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T); // queued tori belong to the frame that ends here
-            V3 c0 = ld3(R.w + 1), ax = ld3(R.w + 4), x = sp - c0;
+            V3 c0 = V3{ prec_w(R, 1), prec_w(R, 2), prec_w(R, 3) }, ax = V3{ prec_w(R, 4), prec_w(R, 5), prec_w(R, 6) }, x = sp - c0;
             F.xa = dot(x, ax); F.da = dot(d, ax);
             V3 u = F.xa * ax - x, v = F.da * ax - d;
             F.a = dot(v, v); F.hb = dot(u, v); F.uu = dot(u, u); F.xd = dot(x, d); F.xx = dot(x, x);
             F.ida = rt_rcp(F.da); F.ia = rt_rcp(F.a); F.sda = isgn(F.da);
             if (mlo & (1u << 16)) { // bounding box of the members: radius <= sqrt(w7), w8 <= axial <= w9.  Nobody gets there before its best hit: skip them all
-                const double a_lo = R.w[8], a_hi = R.w[9];
+                const double a_lo = prec_w(R, 8), a_hi = prec_w(R, 9);
                 const double ta = (a_lo - F.xa) * F.ida, tb = (a_hi - F.xa) * F.ida;
                 double lo = fmin(ta, tb), hi = fmax(ta, tb);
                 if (RT_ANY(F.sda == 0)) { if (F.sda == 0) { const bool in = (F.xa >= a_lo) & (F.xa <= a_hi); lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; } }
-                const double disc = F.hb * F.hb - F.a * (F.uu - R.w[7]), sq = rt_sqrt(disc);
+                const double disc = F.hb * F.hb - F.a * (F.uu - prec_w(R, 7)), sq = rt_sqrt(disc);
                 lo = fmax(lo, (-F.hb - sq) * F.ia); hi = fmin(hi, (sq - F.hb) * F.ia); // NaN (tangent, or ray along the axis) leaves the bound as it is
                 lo = fmax(lo, 0.0); hi = fmin(hi, h.l);
                 const bool reach = act & (disc >= 0) & (lo <= hi);
@@ -787,7 +796,7 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
             const double te = h.l;
             const double r2e = (F.a * te + 2 * F.hb) * te + F.uu;       // radius^2 is convex along the ray: the largest value is at an end
             const double ae = F.xa + F.da * te;                          // NaN (0 * inf) fails every comparison: the ray counts as reaching
-            const bool out = (fmax(F.uu, r2e) < R.w[7]) | (fmax(F.xa, ae) < R.w[8]) | (fmin(F.xa, ae) > R.w[9]);
+            const bool out = (fmax(F.uu, r2e) < prec_w(R, 7)) | (fmax(F.xa, ae) < prec_w(R, 8)) | (fmin(F.xa, ae) > prec_w(R, 9));
             if (!RT_ANY(act & !out)) i += (int)((mlo >> 4) & 0xFFFu);
             continue;
         }
@@ -800,11 +809,11 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
         }
         double l0 = NAN, l1 = NAN; int o0 = 0, o1 = 0; bool ok0 = false, ok1 = false;
         if (kind == PK_PLANE) {
-            l0 = (R.w[1] - F.xa) * F.ida; o0 = -(int)R.w[2] * F.sda; ok0 = F.sda != 0;
+            l0 = (prec_w(R, 1) - F.xa) * F.ida; o0 = -(int)prec_w(R, 2) * F.sda; ok0 = F.sda != 0;
             frame_candidates<false>(G, P, F, R, mlo, mhi, sp, d, six_last, act, l0, l1, o0, o1, ok0, ok1, h);
             continue;
         } else if (kind == PK_CYL) {
-            const double rad = R.w[1], c = F.uu - R.w[2], disc = F.hb * F.hb - F.a * c;
+            const double rad = prec_w(R, 1), c = F.uu - prec_w(R, 2), disc = F.hb * F.hb - F.a * c;
             const double sq = rt_sqrt(disc);
             l0 = (sq - F.hb) * F.ia; l1 = (-F.hb - sq) * F.ia;
             o0 = rad > 0 ? -1 : 1; o1 = -o0; ok0 = ok1 = sq > 0;
@@ -812,13 +821,13 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
                 if (F.a == 0) { l0 = l1 = (F.hb != 0) ? -0.5 * c / F.hb : NAN; o0 = o1 = -isgn(F.hb * rad); ok0 = o0 != 0; ok1 = false; }
             }
         } else if (kind == PK_SPHERE) {
-            const double t = R.w[1], rad = R.w[2], B = F.xd - t * F.da, C = (F.xx - 2 * t * F.xa) + R.w[3], D = B * B - C;
+            const double t = prec_w(R, 1), rad = prec_w(R, 2), B = F.xd - t * F.da, C = (F.xx - 2 * t * F.xa) + prec_w(R, 3), D = B * B - C;
             const double sq = rt_sqrt(D);
             l0 = sq - B; l1 = -B - sq;
             o0 = rad > 0 ? -1 : 1; o1 = -o0; ok0 = ok1 = sq > 0;
         } else if (kind == PK_QUAD) {
-            const double al = R.w[1], ga = R.w[2], pa = R.w[3];
-            const double aq = al * F.a + ga * F.da * F.da, b = 2 * (al * F.hb + ga * F.xa * F.da) + pa * F.da, c = al * F.uu + (ga * F.xa + pa) * F.xa + R.w[4];
+            const double al = prec_w(R, 1), ga = prec_w(R, 2), pa = prec_w(R, 3);
+            const double aq = al * F.a + ga * F.da * F.da, b = 2 * (al * F.hb + ga * F.xa * F.da) + pa * F.da, c = al * F.uu + (ga * F.xa + pa) * F.xa + prec_w(R, 4);
             const double sq = rt_sqrt(b * b - 4 * aq * c), ia = 0.5 * rt_rcp(aq);
             l0 = (sq - b) * ia; l1 = (-b - sq) * ia;
             o0 = -1; o1 = 1; ok0 = ok1 = sq > 0; // d.(2pQ + P) = b + 2 l aq = +-sqrt(discriminant)
@@ -828,15 +837,15 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
                 else if (aq == 0) { ok0 = ok1 = false; }
             }
         } else { // PK_TORUS: RayToTorus.m:88-159; prefilter and quartic as in generic_surface(), from the frame's quantities
-            const double t = R.w[1], R1 = R.w[2], r2 = R.w[3];
+            const double t = prec_w(R, 1), R1 = prec_w(R, 2), r2 = prec_w(R, 3);
             const int n = (int)((mlo >> 4) & 0xFFFu);
             const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0;
             // slab and annulus that hold the bounded part of the torus: w13 <= axial <= w14 (frame coordinate), radius^2 >= w15,
             // radius <= |R1| + |r2| - the torus' own extent cut down by its range bounds on the host; everything 1e-9 wider
-            const double Ro = (fabs(R1) + fabs(r2)) * (1 + 1e-9), Ri2 = R.w[15];
-            const double ta = (R.w[13] - F.xa) * F.ida, tb = (R.w[14] - F.xa) * F.ida;
+            const double Ro = (fabs(R1) + fabs(r2)) * (1 + 1e-9), Ri2 = prec_w(R, 15);
+            const double ta = (prec_w(R, 13) - F.xa) * F.ida, tb = (prec_w(R, 14) - F.xa) * F.ida;
             double lo = fmin(ta, tb), hi = fmax(ta, tb);
-            if (RT_ANY(F.sda == 0)) { if (F.sda == 0) { const bool in = (F.xa >= R.w[13]) & (F.xa <= R.w[14]); lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; } }
+            if (RT_ANY(F.sda == 0)) { if (F.sda == 0) { const bool in = (F.xa >= prec_w(R, 13)) & (F.xa <= prec_w(R, 14)); lo = in ? -INFINITY : INFINITY; hi = in ? INFINITY : -INFINITY; } }
             const double disc = F.hb * F.hb - F.a * (F.uu - Ro * Ro), sq = rt_sqrt(disc);
             const bool qpos = F.a > 0;
             lo = qpos ? fmax(lo, (-F.hb - sq) * F.ia) : lo; hi = qpos ? fmin(hi, (sq - F.hb) * F.ia) : hi;
@@ -851,7 +860,7 @@ template <bool GENERIC = true> RT_HD void find_hit(const Geom& G, const Prm& P, 
                 if (T.npend + cnt > TQ_SLOTS || T.ntor == TQ_TORI) frame_torus_flush(G, P, F, G.uprog, sp, d, six_last, act, h, T);
                 if (maybe) { // depressed quartic about the point of closest approach to the torus centre
                     const int slot = T.npend + rt_rank(mb);
-                    V3 x = sp - ld3(R.w + 4);
+                    V3 x = sp - V3{ prec_w(R, 4), prec_w(R, 5), prec_w(R, 6) };
                     const double t0 = -dot(x, d);
                     V3 xs = x + t0 * d;
                     const double X2 = dot(xs, xs), xas = xa0 + t0 * F.da, K = X2 + R1 * R1 - r2 * r2, R4 = 4 * R1 * R1;
