@@ -863,7 +863,7 @@ struct rt_ctx {
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, seg_per_cu = 8; bool seg_auto = true; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
+    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, hit_split_lanes = 12, seg_per_cu = 8; bool seg_auto = true; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
     // second lane of large tally-only runs (run_trace_lanes): a context of its own that borrows this one's geometry
     // (off by default: the launches of two lanes overlap, which is what it is for, and per-kernel times then mean little)
@@ -976,6 +976,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "level_min_rays") ctx->level_min_rays = (int64_t)value;
     else if (k == "hit_blocks_per_cu") ctx->hit_blocks_per_cu = (int)value;
     else if (k == "hit_split") ctx->hit_split = (int)value;
+    else if (k == "hit_split_lanes") ctx->hit_split_lanes = std::max(1, (int)value);
     else if (k == "seg_per_cu") { if (!(value >= 1 && value <= 64)) { ctx->err = "rt_set_option: seg_per_cu must be in 1..64"; return -1; } ctx->seg_per_cu = (int)value; ctx->seg_auto = false; }
     else if (k == "phys_blocks_per_cu") ctx->phys_blocks_per_cu = (int)value;
     else if (k == "defer_unified") ctx->defer_unified = value != 0;
@@ -1335,7 +1336,12 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 // counts are read once.  Only where rays cannot multiply (single child) and nothing per step leaves the device.
                 const int batch = (single && !full && live < ctx->sync_rays_max) ? std::max(1, std::min(ctx->sync_every, MAX_BATCH)) : 1;
                 const int nb = (int)std::min<int64_t>(batch, std::min<int64_t>(K, ctx->level_steps) - k0);
-                const int split = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->hit_split, (live / nseg + BLOCK - 1) / BLOCK));
+                // Blocks of the nearest-hit launch per segment: one per tile of 256 rays (up to hit_split) when the launch has the
+                // GPU to itself.  Beside another lane's physics launches a dozen longer-lived blocks per segment do better
+                // (+2-3 % from 16M rays: blocks that end every few microseconds keep taking the registers a physics block
+                // - four waves of 199 - is waiting for); powers of two are slow (16: -2 %, 64: -6 %).
+                const int64_t tiles = (live / nseg + BLOCK - 1) / BLOCK;
+                const int split = (int)std::max<int64_t>(1, std::min<int64_t>((ctx->pair && tiles >= 32) ? std::min(ctx->hit_split, ctx->hit_split_lanes) : ctx->hit_split, tiles));
                 for (int j = 0; j < nb; j++) {
                     const int k = k0 + j;
                     a.step = k; a.cnt_in = nullptr; a.n_in = live; a.out = q[cur]; a.tail = ctx->d_lvl + k + 1; a.lean_hash = lean_hash_of(k);
@@ -1499,7 +1505,7 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
         l->has_rayleigh = ctx->has_rayleigh; l->has_unified = ctx->has_unified; l->defer_unified = ctx->defer_unified; l->S = ctx->S; l->lut_n = ctx->lut_n;
         l->nodice_chunk = ctx->nodice_chunk; l->refill_min = ctx->refill_min; l->blocks_per_cu = ctx->blocks_per_cu; l->lds_budget = ctx->lds_budget;
         l->level_steps = ctx->level_steps; l->level_min_rays = ctx->level_min_rays; l->hit_blocks_per_cu = ctx->hit_blocks_per_cu; l->phys_blocks_per_cu = ctx->phys_blocks_per_cu;
-        l->hit_split = ctx->hit_split; l->seg_per_cu = ctx->seg_per_cu; l->seg_auto = ctx->seg_auto; l->sync_every = ctx->sync_every; l->sync_rays_max = ctx->sync_rays_max;
+        l->hit_split = ctx->hit_split; l->hit_split_lanes = ctx->hit_split_lanes; l->seg_per_cu = ctx->seg_per_cu; l->seg_auto = ctx->seg_auto; l->sync_every = ctx->sync_every; l->sync_rays_max = ctx->sync_rays_max;
         l->upload_chunk = ctx->upload_chunk; l->stream_overlap = ctx->stream_overlap;
     }
     const size_t W = ctx->workspace_bytes;
