@@ -1311,7 +1311,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             // one block of the physics kernel per segment: enough of them to fill the machine once the rays have multiplied
             // Single-child runs up to 16M rays: two segments per CU, which is one resident round of the physics kernel (2 blocks per
             // CU at its register budget) - measured against 8 per CU: +24 % at 1M rays, +12 % at 4M, +3 % at 16M, -2 % at 33M
-            const int spc = (single && ctx->seg_auto && m <= ((int64_t)1 << 24)) ? std::min(2, ctx->seg_per_cu) : ctx->seg_per_cu;
+            const int spc = (single && ctx->seg_auto && (m <= ((int64_t)1 << 24) || ctx->pair)) ? std::min(2, ctx->seg_per_cu) : ctx->seg_per_cu; // (beside another lane two stay better above 16M too: +3-4 % at 50M and 67M rays)
             const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * spc, ((single ? m : std::min<int64_t>(q_cap, 64 * m)) + 511) / 512));
             const int64_t seg_fill = (m + nseg - 1) / nseg;
             const int64_t seg_cap = single ? seg_fill : std::max<int64_t>(seg_fill, (q_cap - nseg) / nseg); // rays that split: room to grow
