@@ -1575,8 +1575,9 @@ RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
     double linpol = sqrt(r.s1 * r.s1 + r.s2 * r.s2), frac = linpol / r.s0;
     double phi = TWO_PI * u2;
     if (frac > u1) {
-        // an s2 that is zero up to rounding must not pick the branch of atan2 (s1 < 0: +-pi) by the sign of its noise
-        double s2c = (fabs(r.s2) <= 1e-12 * fabs(r.s1)) ? 0.0 : r.s2;
+        // an s2 that is zero up to noise must not pick the branch of atan2 (s1 < 0: +-pi) by the sign of that noise (1e-9 of
+        // s1 after near-normal incidence, where the plane of incidence is ill-defined); the oracle has the same rule
+        double s2c = (fabs(r.s2) <= 1e-8 * fabs(r.s1)) ? 0.0 : r.s2;
         double ang = 0.5 * atan2(s2c, r.s1), pu = (double)prec * u2;
         int ix = (int)floor(pu) + 1;
         if (ix > prec) ix = prec;
