@@ -1575,10 +1575,11 @@ RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
     double linpol = sqrt(r.s1 * r.s1 + r.s2 * r.s2), frac = linpol / r.s0;
     double phi = TWO_PI * u2;
     if (frac > u1) {
-        // an s2 that is zero up to noise must not pick the branch of atan2 (s1 < 0: +-pi) by the sign of that noise (1e-9 of
-        // s1 after near-normal incidence, where the plane of incidence is ill-defined); the oracle has the same rule
-        double s2c = (fabs(r.s2) <= 1e-8 * fabs(r.s1)) ? 0.0 : r.s2;
-        double ang = 0.5 * atan2(s2c, r.s1), pu = (double)prec * u2;
+        // The angle of the polarisation axis, atan2(s2, s1) / 2 up to a multiple of pi (an axis: same state, same
+        // distribution), taken with the cut of atan2 at s1 = 0, s2 > 0 instead of s2 = 0, s1 < 0 - where light sits after
+        // every s-polarising Fresnel step with an s2 that is zero up to noise, whose sign would pick a scattered direction
+        // or its mirror image.  The oracle does the same (oracle/rt_oracle.c, where the noise is explained).
+        double ang = 0.5 * atan2(r.s1, -r.s2) - 0.25 * 3.14159265358979323846, pu = (double)prec * u2;
         int ix = (int)floor(pu) + 1;
         if (ix > prec) ix = prec;
         double ixf = pu - (double)(ix - 1), a0 = lut[ix - 1], a1 = lut[ix];
