@@ -1592,8 +1592,12 @@ RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
     V3 oref = r.pol, operp = cross(r.d, r.pol);
     r.pol = c * oref + s * operp;
     V3 nperp = cross(r.d, r.pol);
-    double a = r.s1 / r.s0, z = (2 - a) * (1 - 2 * u3), sq = sqrt(z * z + (1 - a) * (1 - a) * (1 - a) / (1 + a));
-    double A = (double)isgn(z + sq) * cbrt(fabs(z + sq)), B = (double)isgn(z - sq) * cbrt(fabs(z - sq));
+    // cos(theta) = (cbrt(z + sq) + cbrt(z - sq)) / cbrt(1 + a) with sq = sqrt(z^2 + w): for a -> 1 (w -> 0) one of the two
+    // arguments is a difference of equal numbers; it is taken from the other through (z + sq)(z - sq) = -w, as in the oracle
+    // (oracle/rt_oracle.c has the story)
+    double a = r.s1 / r.s0, w = (1 - a) * (1 - a) * (1 - a) / (1 + a), z = (2 - a) * (1 - 2 * u3), sq = sqrt(z * z + w), zp, zm;
+    if (z >= 0) { zp = z + sq; zm = zp != 0 ? -w / zp : 0.0; } else { zm = z - sq; zp = -w / zm; }
+    double A = (double)isgn(zp) * cbrt(fabs(zp)), B = (double)isgn(zm) * cbrt(fabs(zm));
     double ct = (A + B) / cbrt(1 + a), st = sqrt(1 - ct * ct);
     Ray10 o = r;
     o.d = ct * r.d + (st * c) * oref + (st * s) * operp;
