@@ -86,6 +86,7 @@ __device__ __noinline__ SinCos rt_sincos_call(double x) { // out of line: ten po
 RT_HD void rt_sincos(double x, double* sn, double* cs) { const SinCos r = rt_sincos_call(x); *sn = r.s; *cs = r.c; }
 __device__ __noinline__ double rt_log(double x) { return log(x); } // the library's, out of line for the same reason
 __device__ __noinline__ double rt_exp(double x) { return exp(x); }
+__device__ __noinline__ double rt_cbrt(double x) { return cbrt(x); }
 #else
 RT_HD double rt_rsqrt(double x) { return 1.0 / sqrt(x); }
 RT_HD double rt_fdiv(double a, double b) { return a / b; }
@@ -93,6 +94,7 @@ RT_HD double rt_fsqrt(double x) { return sqrt(x); }
 RT_HD void rt_sincos(double x, double* sn, double* cs) { sincos(x, sn, cs); }
 RT_HD double rt_log(double x) { return log(x); }
 RT_HD double rt_exp(double x) { return exp(x); }
+RT_HD double rt_cbrt(double x) { return cbrt(x); }
 #endif
 RT_HD V3 normalized_if(V3 a) {
     // no FMA contraction here either: normalising d and -d at two places of the code must give exactly opposite vectors,
@@ -1579,7 +1581,7 @@ RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
         // distribution), taken with the cut of atan2 at s1 = 0, s2 > 0 instead of s2 = 0, s1 < 0 - where light sits after
         // every s-polarising Fresnel step with an s2 that is zero up to noise, whose sign would pick a scattered direction
         // or its mirror image.  The oracle does the same (oracle/rt_oracle.c, where the noise is explained).
-        double ang = 0.5 * atan2(r.s1, -r.s2) - 0.25 * 3.14159265358979323846, pu = (double)prec * u2;
+        double ang = 0.5 * atan2_atom(r.s1, -r.s2) - 0.25 * 3.14159265358979323846, pu = (double)prec * u2;
         int ix = (int)floor(pu) + 1;
         if (ix > prec) ix = prec;
         double ixf = pu - (double)(ix - 1), a0 = lut[ix - 1], a1 = lut[ix];
@@ -1597,8 +1599,8 @@ RT_HD Ray10 rayleigh(Rng& g, const Ray10& in, const double* lut, int prec) {
     // (oracle/rt_oracle.c has the story)
     double a = r.s1 / r.s0, w = (1 - a) * (1 - a) * (1 - a) / (1 + a), z = (2 - a) * (1 - 2 * u3), sq = sqrt(z * z + w), zp, zm;
     if (z >= 0) { zp = z + sq; zm = zp != 0 ? -w / zp : 0.0; } else { zm = z - sq; zp = -w / zm; }
-    double A = (double)isgn(zp) * cbrt(fabs(zp)), B = (double)isgn(zm) * cbrt(fabs(zm));
-    double ct = (A + B) / cbrt(1 + a), st = sqrt(1 - ct * ct);
+    double A = (double)isgn(zp) * rt_cbrt(fabs(zp)), B = (double)isgn(zm) * rt_cbrt(fabs(zm));
+    double ct = (A + B) / rt_cbrt(1 + a), st = sqrt(1 - ct * ct);
     Ray10 o = r;
     o.d = ct * r.d + (st * c) * oref + (st * s) * operp;
     o.pol = cross(nperp, o.d);
