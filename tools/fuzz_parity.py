@@ -36,9 +36,11 @@ def scene(rng):
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed0)
     only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case (the random draws of the others are still made)
     bad = 0; t0 = time.time()
+    rng_l = np.random.default_rng(seed0 + 1)  # (a stream of its own: the cases of a seed stay what they were before lanes were drawn)
     for ci in range(n_cases):
         sl, origin = scene(rng)
         n = int(rng.choice([300, 5000, 40000]))
@@ -47,6 +49,9 @@ def main():
         K = int(rng.choice([3, 5])); tir = float(rng.choice([-1.0, 0.5])); thr = float(rng.choice([1e-9, 1e-3]))  # not 0: children of intensity ~1e-17 (rounding noise) would be followed or not by the last bit
         opts = dict(level_steps=int(rng.choice([0, 2, 1000])), level_min_rays=0, defer_unified=int(rng.random() < 0.5), frames=int(rng.random() < 0.8))
         seed = int(rng.integers(0, 1 << 30))
+        lanes = int(rng_l.choice([1, 2, 3]))
+        if lanes > 1:   # tally-only single-child runs with device final rows take the lanes; everything else ignores the option
+            opts.update(lanes=lanes, lanes_min_rays=0, lanes_alternate=int(rng_l.random() < 0.7))
         args = (K, 1e-7, np.array([thr, thr]), tir, full, single, False)
         if only >= 0 and ci != only:
             continue
@@ -55,7 +60,10 @@ def main():
         try:
             for k, v in opts.items():
                 c.set_option(k, v)
-            out = RayTracer2(sp, rays.copy(), sl, *args, seed=seed, compat="matlab", ctx=c, return_final=True)
+            laned = lanes > 1 and single and not full   # (the lanes take final rows only where they stay on the device)
+            out = RayTracer2(sp, rays.copy(), sl, *args, seed=seed, compat="matlab", ctx=c, return_final="device" if laned else True)
+            if laned:
+                out = list(out); out[3] = out[3].cpu().numpy()
             live, scat = c.step_counts(K)
         finally:
             c.close()
