@@ -265,7 +265,7 @@ def main():
         }
         if table_sum[0] is not None:
             out["config"]["allreduced_table_sum_last_step"] = table_sum[0]
-        if world == 1 and lanes != 1 and not a.no_one_lane and cam is None and h_sp is None and (flags & _lib.FLAG_SINGLECHILD):
+        if world == 1 and lanes != 1 and not a.no_one_lane and cam is None and h_sp is None:
             # Not the headline value: the same K steps again with one lane, every launch alone on the GPU - the per-kernel times
             # and the roofline of the dominant kernel without the other lane's launches beside it.
             ctx.set_option("lanes", 1)

@@ -190,7 +190,7 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
  * launch per queue segment: alone on the GPU, default 128 = one per tile of 256 rays; beside another lane's physics launches, default 12), "seg_per_cu" (queue segments per CU; default
  * 2 for single-child runs up to 16M rays, else 8), "sync_every" / "sync_rays_max" (tally-only single-child runs below that
  * many live rays launch up to that many steps between two host synchronisations; 8 / 16M), "lanes" / "lanes_min_rays" /
- * "lanes_alternate" (tally-only runs of at least that many rays are traced as that many parts (1..4) at the same time, each on
+ * "lanes_alternate" (tally-only runs - dice or ray splitting - of at least that many rays are traced as that many parts (1..4) at the same time, each on
  * a stream and host thread of its own by a context that shares the geometry, taking turns with the nearest-hit launch so
  * that it runs beside the other lane's physics launches: +10 % at 33.5M rays; per-kernel timings (rt_result_timing*) are
  * then sums over launches that overlap in time; default 2 / 2M / 1), "frames" (0: the

@@ -1484,10 +1484,11 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 // across the streams) - so that it runs beside the other lane's physics and not beside its twin: 33.5 M rays
 // 5.58e9 -> 6.15e9 interactions/s (left to chance, without the turns: 5.90e9); +9 % down to 2 M rays.  Three and four
 // lanes are slower than two (each launch then shares the registers of a SIMD with two others).  Rays never interact and
-// are keyed by ray id, so the split changes no result.  Tally-only and device-final-row runs only.
+// are keyed by ray id, so the split changes no result.  Tally-only and device-final-row runs only, dice or ray splitting.
 static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm) {
     const bool full = prm->flags & RT_FLAG_FULL_OUTPUT, single = prm->flags & RT_FLAG_SINGLECHILD, wantfin = prm->flags & RT_FLAG_FINAL_ROWS;
-    const bool eligible = ctx->lanes >= 2 && !ctx->is_lane && (mode == 0 || mode == 2) && single && !full && !(prm->follow_threshold[1] < 0) && (!wantfin || ctx->d_fin_user) &&
+    const bool eligible = ctx->lanes >= 2 && !ctx->is_lane && (mode == 0 || mode == 2) && !full && // (ray-splitting runs as well: 6.56e9 -> 7.50e9 interactions/s on the arbc_nodice workload)
+                          !(prm->follow_threshold[1] < 0) && (!wantfin || ctx->d_fin_user) &&
                           ctx->level_steps > 0 && n >= ctx->lanes_min_rays && !ctx->sink && ctx->d_surf && prm->max_scatters >= 1 && prm->max_scatters <= 4094;
     if (!eligible) return run_trace(ctx, mode, h_start, h_rays, d_soa, origin, n, prm);
     const int L = std::min(ctx->lanes, 4);

@@ -80,6 +80,19 @@ def test_steps_between_host_syncs_and_segment_count_change_nothing():
         assert t.shape == tabs[0].shape and np.allclose(t, tabs[0], rtol=1e-9, atol=1e-9)
 
 
+def test_ray_splitting_runs_take_the_lanes_too():
+    """no-dice mode: both children are followed, the halves of the initial rays are traced as two lanes; tables to 1e-9"""
+    sl, origin = cases.coaxial_scene(2)
+    sp, rays = cases.isotropic_rays(30000, 8, origin=tuple(origin), polarized=True)
+    args = (8, 1e-7, [1e-3, 1e-3], -1, False, False, False)
+    one = gpu_with(dict(lanes=1, level_min_rays=0), sp, rays.copy(), sl, *args, seed=9, compat="matlab")
+    two = gpu_with(dict(lanes=2, lanes_min_rays=1000, level_min_rays=0), sp, rays.copy(), sl, *args, seed=9, compat="matlab")
+    ref = O.trace(sp, rays.copy(), sl, *args, seed=9, compat="matlab")
+    assert one.absorption_table.any() and one.absorption_table.shape == two.absorption_table.shape == ref.absorption_table.shape
+    assert np.allclose(one.absorption_table, two.absorption_table, rtol=1e-9, atol=1e-9)
+    assert np.allclose(ref.absorption_table, two.absorption_table, rtol=1e-6, atol=1e-6)
+
+
 def test_two_lanes_write_the_same_device_final_rows():
     """lanes = 2: the second half of the rays is traced by a second context into the same device buffer of final rows"""
     from raytracer_amd.RayTracer2 import Context, RayTracer2

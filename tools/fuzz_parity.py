@@ -50,7 +50,7 @@ def main():
         opts = dict(level_steps=int(rng.choice([0, 2, 1000])), level_min_rays=0, defer_unified=int(rng.random() < 0.5), frames=int(rng.random() < 0.8))
         seed = int(rng.integers(0, 1 << 30))
         lanes = int(rng_l.choice([1, 2, 3]))
-        if lanes > 1:   # tally-only single-child runs with device final rows take the lanes; everything else ignores the option
+        if lanes > 1:   # tally-only runs with device final rows take the lanes; everything else ignores the option
             opts.update(lanes=lanes, lanes_min_rays=0, lanes_alternate=int(rng_l.random() < 0.7))
         args = (K, 1e-7, np.array([thr, thr]), tir, full, single, False)
         if only >= 0 and ci != only:
@@ -60,7 +60,7 @@ def main():
         try:
             for k, v in opts.items():
                 c.set_option(k, v)
-            laned = lanes > 1 and single and not full   # (the lanes take final rows only where they stay on the device)
+            laned = lanes > 1 and not full   # (the lanes take final rows only where they stay on the device)
             out = RayTracer2(sp, rays.copy(), sl, *args, seed=seed, compat="matlab", ctx=c, return_final="device" if laned else True)
             if laned:
                 out = list(out); out[3] = out[3].cpu().numpy()
