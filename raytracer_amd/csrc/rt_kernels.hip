@@ -857,6 +857,7 @@ struct rt_ctx {
     int64_t upload_chunk = (int64_t)1 << 21;
     bool stream_overlap = true; size_t stream_stage_bytes = (size_t)2 << 30, accumulate_stage_bytes = (size_t)256 << 20;
     double kernel_ms = 0; int n_launches = 0;
+    hipEvent_t lane_ev[4][8] = {};                                 // the lanes' turn events (run_trace_lanes), made on first use
     hipEvent_t evb[3 * 16] = {};                                   // per-step timing events of a batch of level steps (run_trace)
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };    // timing events of run_trace / rt_match_endpoints: created once, so that no error path can leak one
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
@@ -941,6 +942,7 @@ extern "C" void rt_free(rt_ctx* ctx) {
     for (int s = 0; s < 2; s++) { if (ctx->in_pin[s]) hipHostFree(ctx->in_pin[s]); if (ctx->ev_up[s]) hipEventDestroy(ctx->ev_up[s]); }
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 3 * MAX_BATCH; i++) if (ctx->evb[i]) hipEventDestroy(ctx->evb[i]);
+    for (auto& row : ctx->lane_ev) for (auto& e : row) if (e) { hipEventDestroy(e); e = nullptr; }
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1526,7 +1528,11 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
     for (int i = 0; i < 4; i++) { pair.rec[i].store(0); pair.done[i].store(0); }
     if (ctx->lanes_alternate) {
         paired = true;
-        for (int i = 0; i < 8 * L && paired; i++) if (hipEventCreateWithFlags(&pair.ev[i / 8][i % 8], hipEventDisableTiming) != hipSuccess) { for (int j = 0; j < i; j++) hipEventDestroy(pair.ev[j / 8][j % 8]); paired = false; }
+        for (int i = 0; i < 8 * L && paired; i++) { // (kept in the context: no event is made or destroyed per call after the first)
+            hipEvent_t& e = ctx->lane_ev[i / 8][i % 8];
+            if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; paired = false; }
+            pair.ev[i / 8][i % 8] = e;
+        }
     }
     if (paired) for (int j = 0; j < L; j++) { lc[j]->pair = &pair; lc[j]->pair_id = j; lc[j]->pair_seq = 0; }
     auto run_lane = [&](int j) {
@@ -1537,7 +1543,6 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
     for (int j = 1; j < L; j++) th.emplace_back(run_lane, j);
     run_lane(0);
     for (auto& t : th) t.join();
-    if (paired) for (int i = 0; i < 8 * L; i++) hipEventDestroy(pair.ev[i / 8][i % 8]);
     ctx->workspace_bytes = W;
     for (int j = 0; j < L; j++) { lc[j]->pair = nullptr; lc[j]->raw_tally = false; }
     for (int j = 1; j < L; j++) { rt_ctx* l = lc[j]; l->d_surf = l->d_recs = l->d_prog = l->d_lut = l->d_cam = nullptr; l->d_smeta = nullptr; l->d_fin_user = nullptr; } // not the lanes' to free
