@@ -96,7 +96,11 @@ def cpu_baseline(prog, origin, kw, seed, target_seconds=12.0):
     except OSError:
         pass
     return {"value": inter / t_used, "unit": "interactions/s", "cores": threads, "cpu": cpu, "kind": "port",
-            "sample": "%d rays (%d interactions) of the same workload through oracle/rt_oracle.c, %.1f s" % (done * n, inter, t_used)}
+            "sample": "%d rays (%d interactions) of the same workload through oracle/rt_oracle.c, %.1f s" % (done * n, inter, t_used),
+            "note": "the builder's own C restatement (OpenMP), not a timing of the reference: the reference's numpy RayTracer2 cannot run this geometry "
+                    "(torus and quadsurface are never imported, python/RayToShape.py:23,27; parity of this figure with the reference is unpinned). The only link "
+                    "to the real reference is at S = 2 (SURVEY configs 1-2, tools/cpu_ratio.py, build container): there the numpy reference makes 4.9e5 and "
+                    "4.8e5 interactions/s on one core and this restatement 3.9x and 5.9x that on one thread"}
 
 
 def main():
@@ -174,9 +178,10 @@ def main():
         else:
             ctx._check(ctx.L.rt_trace_point_source(ctx.h, org, a.rays, C.byref(prm)))
         live, scat = ctx.step_counts(kw["K"])
-        if dist is not None:  # the one collective of the path: the tallies of all ranks (multigpu.sharded_trace does the same)
-            tab = np.zeros((kw["K"], 5, S, 2)); t_ = ctx.results(False, False, a.rays)["table"]; tab[:t_.shape[0]] = t_
-            tt = torch.from_numpy(tab).to("cuda" if backend == "nccl" else "cpu")
+        if dist is not None:  # the one collective of the path: the tallies of all ranks, all-reduced from the device table as it is (multigpu.allreduce_table does the same)
+            tt = ctx.table_device(kw["K"])
+            if backend != "nccl":
+                tt = tt.cpu()
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             table_sum[0] = float(tt.sum())
         ms = C.c_double(); nl = C.c_int32(); ctx.L.rt_result_timing(ctx.h, C.byref(ms), C.byref(nl))
@@ -213,8 +218,9 @@ def main():
     if rank == 0:
         fpi = flop_per_interaction(prog[0])
         fph = fpi - FLOP_PHYSICS  # nearest-hit search only: per ray and step, all surfaces
-        kernel_s = kms / 1e3
-        path = (inter * fpi / kernel_s) / 1e12 if kernel_s > 0 else 0.0
+        # the whole path by the same convention: over the wall time of the timed region (the launches of two lanes overlap:
+        # the sum of their event-bracketed times is longer than the step)
+        path = (inter * fpi / dt) / 1e12 if dt > 0 else 0.0
         names = ("k_trace", "k_level_hit", "k_level_phys")
         hit_ms, hit_n = by_kernel[1]
         # dominant kernel: k_level_hit (nearest hit over all surfaces for the live rays of one step, one launch per step)
@@ -250,16 +256,20 @@ def main():
                                       else "camera rays generated on the device", kw["K"], kw["thr"][0], a.rays),
                        "rays_per_step_per_gpu": a.rays, "lanes": lanes, "surfaces": S, "interactions_per_ray": inter / (a.steps * a.rays),
                        "ray_surface_tests_per_s": inter_all * S / dt},
-            "roofline": dict({"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+            "roofline": dict({"bound": "fp64_valu", "achieved": counter_tflops if counter_tflops is not None else ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": (counter_tflops if counter_tflops is not None else ach) / FP64_VALU_PEAK_TFLOPS,
+                              "basis": "executed" if counter_tflops is not None else "algorithmic (profiles/counters.json is not from these kernel sources: no executed-flop figure)",
+                              "algorithmic_achieved": ach, "algorithmic_frac": ach / FP64_VALU_PEAK_TFLOPS,
                               "traffic": traffic, "counter_tflops": counter_tflops, "valu_issue_frac": valu_issue_frac,
-                              "note": "achieved/frac follow the ALGORITHMIC flop convention of SURVEY.md 8a/8d (every surface counted for every ray; the frame "
-                                      "program exists to skip most of that work, so this is not executed work). counter_tflops = FP64 flops the kernel executed "
-                                      "(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2) per second, valu_issue_frac = SQ_ACTIVE_INST_VALU cycles / "
-                                      "(GRBM_GUI_ACTIVE x SIMDs), traffic = HBM bytes per launch (TCC_EA0 read/write requests): profiles/counters.json, "
-                                      "null when that file is not from these kernel sources. No dense contraction: MFMA unused. With lanes = 2 "
-                                      "avg_launch_ms is the event-bracketed time of a launch that shares the GPU with the other lane's physics "
-                                      "launches (that overlap is the point of the lanes); `one_lane` has the same figures for launches that run alone"}, **dom),
-            "roofline_path": {"achieved": path, "frac": path / FP64_VALU_PEAK_TFLOPS, "flop_per_interaction": fpi, "kernel_ms_per_step": kms / a.steps,
+                              "note": "achieved/frac = FP64 flops the kernel EXECUTED per second (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2, per unit "
+                                      "from the rocprofv3 --pmc passes of this command in profiles/counters.json, x units per launch / measured launch time) over "
+                                      "the FP64 vector peak. algorithmic_* follow the flop CONVENTION of SURVEY.md 8a/8d (every surface counted for every ray; the "
+                                      "frame program exists to skip most of that work, so it is not executed work and can exceed 1). valu_issue_frac = "
+                                      "SQ_ACTIVE_INST_VALU cycles / (GRBM_GUI_ACTIVE x SIMDs), traffic = HBM bytes per launch (TCC_EA0 read/write requests). No dense "
+                                      "contraction: MFMA unused. With lanes = 2 avg_launch_ms is the event-bracketed time of a launch that shares the GPU with the "
+                                      "other lane's physics launches (that overlap is the point of the lanes); `one_lane` has the same figures for launches that run alone"}, **dom),
+            "roofline_path": {"achieved": path, "frac": path / FP64_VALU_PEAK_TFLOPS, "basis": "algorithmic flop convention over the wall time of the timed region",
+                              "flop_per_interaction": fpi, "kernel_ms_per_step": kms / a.steps, "kernel_ms_note": "sum of event-bracketed launch times; with lanes = 2 launches overlap and the sum exceeds the step",
                               "by_kernel": {n: {"ms_per_step": by_kernel[j][0] / a.steps, "launches_per_step": by_kernel[j][1] / a.steps}
                                             for j, n in enumerate(names)}},
         }
@@ -282,9 +292,11 @@ def main():
                    "note": "same workload, rt_set_option(lanes, 1); measured after the timed region, not part of `value`"}
             if h_n > 0 and h_ms > 0:
                 ach1 = (hit_units[0] * fph / (h_ms / 1e3)) / 1e12
+                ct1 = (counter_tflops * dom["avg_launch_ms"] / dom["units_per_launch"] * (hit_units[0] / h_n) / (h_ms / h_n)) if counter_tflops is not None else None
                 one["roofline"] = {"kernel": "k_level_hit", "launches": h_n, "avg_launch_ms": h_ms / h_n, "units_per_launch": hit_units[0] / h_n,
-                                   "achieved": ach1, "frac": ach1 / FP64_VALU_PEAK_TFLOPS,
-                                   "counter_tflops": (counter_tflops * dom["avg_launch_ms"] / dom["units_per_launch"] * (hit_units[0] / h_n) / (h_ms / h_n)) if counter_tflops is not None else None}
+                                   "achieved": ct1 if ct1 is not None else ach1, "frac": (ct1 if ct1 is not None else ach1) / FP64_VALU_PEAK_TFLOPS,
+                                   "basis": "executed" if ct1 is not None else "algorithmic", "algorithmic_achieved": ach1, "algorithmic_frac": ach1 / FP64_VALU_PEAK_TFLOPS,
+                                   "counter_tflops": ct1}
             out["one_lane"] = one
         if not a.no_cpu_baseline and world == 1 and cam is None:
             out["cpu_baseline"] = cpu_baseline(prog, origin, kw, a.seed)

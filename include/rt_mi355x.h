@@ -93,6 +93,9 @@ typedef struct rt_params {
                                 (RefractionReflectionAtInterface.m:217-225) */
     uint64_t seed;           /* Philox key */
     int64_t ray_id_base;     /* global id of ray 0 of this call (sharding over GPUs / chunks) */
+    int64_t ray_id_stride;   /* id of ray i = ray_id_base + i * stride; 0 = 1.  G for a rank that takes every G-th ray of a
+                                spatially ordered source (camera pixels, GenerateRaysFromCamera.m:44-46), so that in
+                                ray-splitting mode every rank gets the same mix of long and short lineages */
 } rt_params;
 
 /* One record per interaction = one row of the reference's rayInterfaces arrays (python/rayInterfaces.py:4-20),
@@ -121,7 +124,7 @@ typedef struct rt_ctx rt_ctx;
 /* Create a context on HIP device `device`.  Replaces nothing in the reference (it has no device). */
 int rt_init(int device, rt_ctx** out);
 void rt_free(rt_ctx* ctx);
-const char* rt_last_error(rt_ctx* ctx); /* ctx may be NULL: last error of rt_init */
+const char* rt_last_error(rt_ctx* ctx); /* ctx may be NULL: the calling thread's last rt_init error */
 
 /* Upload the geometry.  Replaces the per-call walk over `surfacelist` objects (RayTracer2.py:234-248, 288-374). */
 int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
@@ -138,8 +141,10 @@ int rt_trace(rt_ctx* ctx, const double* start, const double* rays, int64_t n, co
  * 3..12 the ten ray columns.  The pointer is a device pointer (e.g. torch tensor.data_ptr()). */
 int rt_trace_device(rt_ctx* ctx, const double* d_soa, int64_t n, const rt_params* prm);
 
-/* rt_trace_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (it has no device and no allocator to avoid).  Tally-only
+/* rt_trace_device for callers that cannot allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc, code that has set up a HIP graph or a pool and must not see it move.  The call itself is BLOCKING and runs
+ * on the context's own stream (it ends with a stream synchronisation and cannot be recorded into a graph capture).
+ * NO COUNTERPART IN THE REFERENCE (it has no device and no allocator to avoid).  Tally-only
  * single-child runs (prm->flags == RT_FLAG_SINGLECHILD, thresholds >= 0), at most RT_NOALLOC_MAX_RAYS rays and
  * RT_NOALLOC_MAX_SCATTERS steps per call; more is refused with an error.  Every device buffer beyond the caller's
  * inputs and outputs (ray queues, nearest hits, ray lists, counters) lives in a static device array of
@@ -178,6 +183,9 @@ typedef struct rt_camera {
 /* One ray per pixel, generated in HBM, traced.  Ray id = ray_id_base + (j-1)*resolution[0] + (i-1), the row order of
  * GenerateRaysFromCamera.m:44-46.  Replaces GenerateRaysFromCamera + the host arrays of BubbleImageCreator.py:129. */
 int rt_trace_camera(rt_ctx* ctx, const rt_camera* cam, const rt_params* prm);
+/* The same for n pixels first, first + stride, ... (stride = prm->ray_id_stride; ray i has id ray_id_base + i * stride): a
+ * rank's share of the sensor, contiguous or interleaved, without host arrays (no reference counterpart). */
+int rt_trace_camera_range(rt_ctx* ctx, const rt_camera* cam, int64_t first, int64_t n, const rt_params* prm);
 /* Rays of pixels [first, first+n) copied to the host in the reference layout, pixels[n][2] = (i, j) 1-based:
  * the return values of GenerateRaysFromCamera.m:6 with the constant columns appended. */
 int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, int64_t n,
@@ -185,7 +193,7 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
 
 /* Tuning knobs (no reference counterpart): "workspace_gb" (device memory for records/queues, default 32),
  * "level_steps" / "level_min_rays" (single-child runs are traced step by step for at most that many steps and while
- * at least that many rays are live, the persistent kernel takes the rest; no cap / 32768), "defer_unified" (0: rays ending
+ * at least that many rays are live, the persistent kernel takes the rest; no cap / 786432), "defer_unified" (0: rays ending
  * on UNIFIED surfaces are not given a physics launch of their own), "hit_split" / "hit_split_lanes" (blocks of the nearest-hit
  * launch per queue segment: alone on the GPU, default 128 = one per tile of 256 rays; beside another lane's physics launches, default 12), "seg_per_cu" (queue segments per CU; default
  * 2 for single-child runs up to 16M rays, else 8), "sync_every" / "sync_rays_max" (tally-only single-child runs below that
@@ -250,6 +258,11 @@ int rt_match_endpoints(rt_ctx* ctx, const double* cam_rows /*[n_cam][RT_FINAL_CO
 int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps);           /* rows of absorption_table (RayTracer2.py:542) */
 int rt_result_table(rt_ctx* ctx, double* table /* [num_steps][5][n_surf][2] */);
 int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live /*[K]*/, int64_t* n_scat /*[K]*/);
+/* The table of the last trace without the trip through host memory: all max_scatters rows [K][5][n_surf][2] (rows of steps
+ * in which nothing scattered, and rows behind num_steps, are zero) copied into the caller's device buffer, and optionally
+ * the counters [2][K] = n_live, n_scat.  For the one collective of a multi-GPU run: the all-reduce of the tallies takes
+ * the device buffer as it is (raytracer_amd/multigpu.py, bench.py --gpus N).  No reference counterpart. */
+int rt_result_table_device(rt_ctx* ctx, double* d_table /* device */, uint64_t* d_step_counts /* device, or NULL */);
 int rt_result_num_records(rt_ctx* ctx, int64_t* n);
 /* records in device order + ordering metadata; the host wrapper sorts them into the reference's order */
 int rt_result_records(rt_ctx* ctx, double* rec /*[n][RT_REC_COLS]*/, int32_t* step /*[n]*/,
@@ -264,6 +277,16 @@ int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_t n, int32_
  * Returns 0, -1 (bad column range) or -2 (record index out of range). */
 int rt_split_record_fields(const double* rows /*[n_rows][RT_REC_COLS]*/, int64_t n_rows, const int64_t* order, int64_t n, int32_t nfields,
                            const int32_t* col0, const int32_t* ncols, double* const* outs);
+/* Host work of the drop-in call, off the interpreter (plain host code, no context).
+ * rt_normalize_rays: the reference normalises the caller's `rays` in place (python/RayTracer2.py:221-222: columns 0-2 and
+ * 3-5, each divided by |sqrt(sum of squares)|); the same operations in the same order, on several host threads.
+ * rt_order_records: the reference's row order (python/RayTracer2.py:531-540: step 0 in input order, step k + 1 =
+ * [refracted children in the order of their parents ; reflected children in the order of their parents]) from the ordering
+ * metadata of rt_result_records: order[0..n) = record indices, step after step; counts[k] = records of step k.  Returns 0,
+ * -1 (bad arguments) or -2 (metadata that is not a tree of that form, e.g. ray ids too sparse for a table: sort instead). */
+int rt_normalize_rays(double* rays /*[n][10]*/, int64_t n);
+int rt_order_records(const int32_t* step, const int64_t* ray_id, const int64_t* parent, const int32_t* flags, int64_t n, int32_t num_steps,
+                     int64_t* order /*[n]*/, int64_t* counts /*[num_steps]*/);
 int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);
 /* Final rows without the trip through host memory (no reference counterpart; the reference's reduction,
  * python/BubbleImageCreator.py:134-165, lives in host arrays): traces with RT_FLAG_FINAL_ROWS write row (ray id -

@@ -27,7 +27,7 @@ COMPAT = {"python": 1, "python-strict": 3, "matlab": 0}
 class Params(C.Structure):
     _fields_ = [("max_scatters", C.c_int32), ("flags", C.c_int32), ("compat", C.c_int32), ("unified_maxiter", C.c_int32),
                 ("min_travel_length", C.c_double), ("follow_threshold", C.c_double * 2), ("tir_handling", C.c_double),
-                ("seed", C.c_uint64), ("ray_id_base", C.c_int64)]
+                ("seed", C.c_uint64), ("ray_id_base", C.c_int64), ("ray_id_stride", C.c_int64)]
 
 
 CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int, C.POINTER(C.c_uint8))
@@ -93,7 +93,7 @@ def build_table(surfacelist, nobulk=False):
 
 def trace(ray_startingpoints, rays, surfacelist, max_scat=10, min_travel_len=np.spacing(1.0), follow_thresh=(0.0, 0.0),
           tir_handling=None, full_output=True, singlechild=True, output_raytable=False, *, compat="python", seed=0,
-          ray_id_base=0, program=None, final=False, unified_maxiter=0):
+          ray_id_base=0, ray_id_stride=1, program=None, final=False, unified_maxiter=0):
     """Run the oracle.  `program=None`: call the surfaces' inbounds lambdas; otherwise (table, atoms, code) from a
     bounds compiler (used to time the oracle without Python in the loop, and to test the compiler)."""
     L = lib()
@@ -120,6 +120,7 @@ def trace(ray_startingpoints, rays, surfacelist, max_scat=10, min_travel_len=np.
     prm.tir_handling = float(tir_handling)
     prm.seed = seed
     prm.ray_id_base = ray_id_base
+    prm.ray_id_stride = ray_id_stride
 
     if program is None:
         table = build_table(surfacelist, nobulk=(compat == "python-strict"))
@@ -172,10 +173,13 @@ def trace(ray_startingpoints, rays, surfacelist, max_scat=10, min_travel_len=np.
     if output_raytable:  # RayTracer2.m:249-253,543-548
         raytable = np.zeros((K + 1, n, 13))
         raytable[0, :, 0:3] = sp; raytable[0, :, 3:13] = ry
+        with np.errstate(all="ignore"):  # RayTracer2.m:244-245: layer 1 holds the rays as normalised
+            raytable[0, :, 3:6] /= np.abs(np.sqrt(np.sum(raytable[0, :, 3:6] ** 2, axis=1, keepdims=True)))
+            raytable[0, :, 6:9] /= np.abs(np.sqrt(np.sum(raytable[0, :, 6:9] ** 2, axis=1, keepdims=True)))
         base = 0 if (cflags & 1) else 1
         for k, ri in enumerate(ris):
             cut = ri.has_reflected == 0
-            ix = np.abs(ri.ray_index[cut]).astype(np.int64) - base - ray_id_base
+            ix = (np.abs(ri.ray_index[cut]).astype(np.int64) - base - ray_id_base) // max(int(ray_id_stride), 1)
             raytable[k + 1, ix, 0:3] = ri.intersection_point[cut]
             raytable[k + 1, ix, 3:13] = ri.refracted_ray[cut]
     out = types.SimpleNamespace(ray_interfaces=ris if full_output else [], absorption_table=table_out, raytable=raytable,

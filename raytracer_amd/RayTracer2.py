@@ -18,7 +18,8 @@ Differences a caller can see, all deliberate (SURVEY.md quirk ledger):
     number of GPUs or on chunking.  `seed=None` draws the seed from numpy's global stream, so `np.random.seed()`
     still makes runs repeatable.
 Keyword-only extras: compat, seed, device, return_final (True: rows as a numpy array; "device": as a torch tensor in
-HBM), ray_id_base, ctx.
+HBM), ray_id_base, ray_id_stride (ray i has the id base + i * stride: a rank's interleaved share), device_table (the
+absorption_table as a torch tensor [max_scat][5][S][2] in HBM, for a device-side all-reduce), ctx.
 """
 import ctypes as C
 
@@ -28,6 +29,7 @@ from . import _lib
 from . import table as _table
 from .rayInterfaces import rayInterfaces
 
+NUMPY_NORMALISE = False   # (tools/bench_dropin.py --numpy-host-work: the caller's rays normalised by the numpy expression, as in round 2)
 COMPAT = {"python": _lib.COMPAT_PY_INDEX, "python-strict": _lib.COMPAT_PY_INDEX | _lib.COMPAT_PY_ROOT2, "matlab": 0}
 _CTX = {}
 
@@ -49,6 +51,7 @@ class Context(object):
         self._geom_key = None
         self._lut_set = False
         self.n_surf = 0
+        self.options = {}
 
     def close(self):
         if self.h:
@@ -64,6 +67,7 @@ class Context(object):
 
     def set_option(self, key, value):
         self._check(self.L.rt_set_option(self.h, key.encode(), float(value)))
+        self.options[key] = float(value)   # what the caller asked for last (RayTracer2 restores "nodice_chunk" from here)
 
     def device_info(self):
         ncu = C.c_int32(); hbm = C.c_int64(); name = C.create_string_buffer(64)
@@ -89,8 +93,9 @@ class Context(object):
             self._geom_key = key
             self._geom_refs = (list(surfacelist), [getattr(s, "inbounds_function", None) for s in surfacelist])
 
-    def params(self, K, flags, compat, min_travel, thr, tir, seed, ray_id_base, unified_maxiter=0):
+    def params(self, K, flags, compat, min_travel, thr, tir, seed, ray_id_base, unified_maxiter=0, ray_id_stride=1):
         p = _lib.Params()
+        p.ray_id_stride = int(ray_id_stride)
         p.max_scatters = int(K); p.flags = int(flags); p.compat = int(compat); p.unified_maxiter = int(unified_maxiter)
         p.min_travel_length = float(min_travel); p.follow_threshold[0] = float(thr[0]); p.follow_threshold[1] = float(thr[1])
         p.tir_handling = float(tir); p.seed = int(seed) & 0xFFFFFFFFFFFFFFFF; p.ray_id_base = int(ray_id_base)
@@ -154,6 +159,17 @@ class Context(object):
     def final_rows_host(self):
         self._check(self.L.rt_set_final_rows_device(self.h, None, 0))
 
+    def table_device(self, K):
+        """the absorption_table of the last trace as a torch tensor [K][5][n_surf][2] on this context's GPU (all K rows; rows
+        of steps in which nothing scattered are zero) - what the all-reduce of a multi-GPU run takes, without a trip
+        through host memory (rt_result_table_device)"""
+        import torch
+        t = torch.empty((int(K), 5, self.n_surf, 2), dtype=torch.float64, device="cuda:%d" % int(self.device))
+        self._check(self.L.rt_result_table_device(self.h, C.c_void_p(t.data_ptr()), None))
+        ns = C.c_int32(); self._check(self.L.rt_result_num_steps(self.h, C.byref(ns)))
+        t.num_steps = ns.value   # the reference's num_scatters: the rows behind it are zero
+        return t
+
     def step_counts(self, K):
         live = np.zeros(K, np.int64); scat = np.zeros(K, np.int64)
         self._check(self.L.rt_result_step_counts(self.h, live.ctypes.data_as(C.POINTER(C.c_int64)), scat.ctypes.data_as(C.POINTER(C.c_int64))))
@@ -209,13 +225,17 @@ def _surface_fingerprint(s):
 
 def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.float64(1)), follow_thresh=np.array([0, 0], dtype=np.float64),
                  tir_handling=[], full_output=False, singlechild=True, *, compat="python", seed=None, device=0, ctx=None, ray_id_base=0,
-                 unified_maxiter=0, device_rows=False):
+                 unified_maxiter=0, device_rows=False, first_pixel=0, n_pixels=None, ray_id_stride=1):
     """The camera run of python/BubbleImageCreator.py:129 without host arrays: rays are generated in HBM from the
     rt_camera `cam` (GenerateRaysFromCamera.make_camera), traced, and reduced to the final row per pixel
-    (BubbleImageCreator.py:149-161).  Returns (absorption_table, final_rows[n_pixels][32], ray_interfaces or [])."""
+    (BubbleImageCreator.py:149-161).  Returns (absorption_table, final_rows[n_pixels][32], ray_interfaces or []).
+    first_pixel / n_pixels / ray_id_stride: a share of the sensor - pixels first, first + stride, ... (ray i has the id
+    ray_id_base + i * stride) - for runs sharded over GPUs (multigpu.sharded_trace_camera)."""
     if np.size(surfacelist) == 0:
         raise Exception('Improper input to RayTracer2')
-    n = int(cam.resolution[0]) * int(cam.resolution[1])
+    npix = int(cam.resolution[0]) * int(cam.resolution[1])
+    whole = n_pixels is None and first_pixel == 0 and ray_id_stride == 1
+    n = npix if n_pixels is None else int(n_pixels)
     st = np.array([[cam.stokes[0]]])
     K, mtl, thr, tir = parse_args(np.hstack([np.zeros((1, 6)), st, np.zeros((1, 3))]), max_scat, min_travel_len, follow_thresh, tir_handling, compat)
     for s in surfacelist:
@@ -229,10 +249,13 @@ def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.flo
     c = ctx if ctx is not None else get_context(device)
     c.set_surfaces(surfacelist, nobulk=(compat == "python-strict"))
     flags = (_lib.FLAG_FULL_OUTPUT if full_output else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | _lib.FLAG_FINAL_ROWS
-    prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
+    prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter, ray_id_stride)
     rows = c.final_rows_device(n) if device_rows else None
     try:
-        c._check(c.L.rt_trace_camera(c.h, C.byref(cam), C.byref(prm)))
+        if whole:
+            c._check(c.L.rt_trace_camera(c.h, C.byref(cam), C.byref(prm)))
+        else:
+            c._check(c.L.rt_trace_camera_range(c.h, C.byref(cam), int(first_pixel), n, C.byref(prm)))
     finally:
         if device_rows:
             c.final_rows_host()
@@ -241,9 +264,35 @@ def trace_camera(cam, surfacelist, max_scat=10, min_travel_len=np.spacing(np.flo
         res["final"] = rows
     ris = []
     if full_output:
-        groups = order_records(res["step"], res["ray"], res["parent"], res["flags"], res["num_steps"])
+        groups = order_groups(res["step"], res["ray"], res["parent"], res["flags"], res["num_steps"])
         ris = c.interfaces(groups)
     return res["table"], res["final"], ris
+
+
+def trace_point_source(origin, n, surfacelist, max_scat=10, min_travel_len=np.spacing(np.float64(1)), follow_thresh=np.array([0, 0], dtype=np.float64),
+                       tir_handling=[], singlechild=True, *, compat="python", seed=None, device=0, ctx=None, ray_id_base=0, ray_id_stride=1,
+                       unified_maxiter=0, device_table=False):
+    """The light-collection run of MATLAB/Examples/RunExamples/RunSBCGeometry.m:45-77 without host arrays: n isotropic
+    unpolarised unit-intensity rays from `origin` are generated in HBM (ray i has the id ray_id_base + i * ray_id_stride and
+    is the same ray whichever call, GPU or chunk makes it) and traced for their tallies.  Returns the absorption_table, or
+    with device_table=True a torch tensor [max_scat][5][S][2] in HBM (Context.table_device)."""
+    if np.size(surfacelist) == 0 or int(n) < 1:
+        raise Exception('Improper input to RayTracer2')
+    K, mtl, thr, tir = parse_args(np.array([[0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0]]), max_scat, min_travel_len, follow_thresh, tir_handling, compat)
+    for s in surfacelist:
+        if not hasattr(s, "unifiedparams") or np.size(s.unifiedparams) == 0:
+            s.unifiedparams = [0, 1, 0, 1, 0]
+        for name in _table.BULK_PROPS:
+            if not hasattr(s, name) or np.size(getattr(s, name)) == 0:
+                setattr(s, name, np.inf)
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) * (2 ** 31) + int(np.random.randint(0, 2 ** 31 - 1))
+    c = ctx if ctx is not None else get_context(device)
+    c.set_surfaces(surfacelist, nobulk=(compat == "python-strict"))
+    prm = c.params(K, _lib.FLAG_SINGLECHILD if singlechild else 0, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter, ray_id_stride)
+    org = (C.c_double * 3)(*[float(x) for x in origin])
+    c._check(c.L.rt_trace_point_source(c.h, org, int(n), C.byref(prm)))
+    return c.table_device(K) if device_table else c.results(False, False, int(n))["table"]
 
 
 class npz_shards(object):
@@ -275,7 +324,7 @@ def _install_sink(c, record_sink, K):
             n = int(n)
             st = np.ctypeslib.as_array(step, shape=(n,))
             ry = np.ctypeslib.as_array(ray, shape=(n,)); pa = np.ctypeslib.as_array(parent, shape=(n,)); fl = np.ctypeslib.as_array(flags, shape=(n,))
-            groups = order_records(st, ry, pa, fl, K)
+            groups = order_groups(st, ry, pa, fl, K)
             record_sink(state["chunk"], int(first), int(nrays), c.interfaces(groups, rec, n))
             state["chunk"] += 1
             return 0
@@ -291,6 +340,22 @@ def get_context(device=0):
     if device not in _CTX:
         _CTX[device] = Context(device)
     return _CTX[device]
+
+
+def order_groups(step, ray, parent, flags, num_steps):
+    """order_records() by the library (rt_order_records: tables instead of sorts, on several host threads); the numpy
+    version below where the library declines (metadata that is not the reference's tree)"""
+    L = _lib.load()
+    n = int(step.shape[0])
+    if n and num_steps and hasattr(L, "rt_order_records"):
+        st = np.ascontiguousarray(step, np.int32); ry = np.ascontiguousarray(ray, np.int64); pa = np.ascontiguousarray(parent, np.int64); fl = np.ascontiguousarray(flags, np.int32)
+        order = np.empty(n, np.int64); counts = np.zeros(int(num_steps), np.int64)
+        I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        if L.rt_order_records(st.ctypes.data_as(I32), ry.ctypes.data_as(I64), pa.ctypes.data_as(I64), fl.ctypes.data_as(I32), n, int(num_steps),
+                              order.ctypes.data_as(I64), counts.ctypes.data_as(I64)) == 0:
+            ends = np.cumsum(counts)
+            return [order[e - c:e] for c, e in zip(counts, ends)]
+    return order_records(step, ray, parent, flags, num_steps)
 
 
 def order_records(step, ray, parent, flags, num_steps):
@@ -338,7 +403,7 @@ def parse_args(rays, max_scat, min_travel_len, follow_thresh, tir_handling, comp
 def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel_len=np.spacing(np.float64(1)),
                follow_thresh=np.array([0, 0], dtype=np.float64), tir_handling=[], full_output=True, singlechild=True,
                output_raytable=False, *, compat="python", seed=None, device=0, return_final=False, ray_id_base=0, ctx=None,
-               unified_maxiter=0, record_sink=None):
+               unified_maxiter=0, record_sink=None, ray_id_stride=1, device_table=False):
     # error check inputs (python/RayTracer2.py:216-217), before any device work
     if np.size(surfacelist) == 0 or np.array(ray_startingpoints).ndim != 2 or np.array(rays).ndim != 2 or \
             np.size(ray_startingpoints, 1) != 3 or np.size(rays, 1) != 10 or np.size(ray_startingpoints, 0) != np.size(rays, 0):
@@ -353,9 +418,13 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     K, mtl, thr, tir = parse_args(ry, max_scat, min_travel_len, follow_thresh, tir_handling, compat)
     # the reference normalises the caller's array in place (python/RayTracer2.py:221-222); keep that visible effect
     if isinstance(rays, np.ndarray) and rays.dtype == np.float64:
-        with np.errstate(all="ignore"):
-            rays[:, 0:3] = rays[:, 0:3] / np.abs(np.sqrt(np.sum(rays[:, 0:3] ** 2, axis=1, keepdims=True)))
-            rays[:, 3:6] = rays[:, 3:6] / np.abs(np.sqrt(np.sum(rays[:, 3:6] ** 2, axis=1, keepdims=True)))
+        L_ = _lib.load()
+        if rays.flags.c_contiguous and rays.flags.writeable and hasattr(L_, "rt_normalize_rays") and not NUMPY_NORMALISE:
+            L_.rt_normalize_rays(_dp(rays), n)   # the same operations on several host threads (the numpy expression takes longer than the trace)
+        else:
+            with np.errstate(all="ignore"):
+                rays[:, 0:3] = rays[:, 0:3] / np.abs(np.sqrt(np.sum(rays[:, 0:3] ** 2, axis=1, keepdims=True)))
+                rays[:, 3:6] = rays[:, 3:6] / np.abs(np.sqrt(np.sum(rays[:, 3:6] ** 2, axis=1, keepdims=True)))
     # missing optional attributes get the reference's defaults on the caller's objects (RayTracer2.py:234-248)
     for s in surfacelist:
         if not hasattr(s, "unifiedparams") or np.size(s.unifiedparams) == 0:
@@ -369,8 +438,9 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     c.set_surfaces(surfacelist, nobulk=(compat == "python-strict"))
     want_rec = bool(full_output or output_raytable)
     flags = (_lib.FLAG_FULL_OUTPUT if want_rec else 0) | (_lib.FLAG_SINGLECHILD if singlechild else 0) | (_lib.FLAG_FINAL_ROWS if return_final else 0)
-    prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter)
+    prm = c.params(K, flags, COMPAT[compat], mtl, thr, tir, seed, ray_id_base, unified_maxiter, ray_id_stride)
     chunk = None
+    chunk_before = c.options.get("nodice_chunk")   # the caller's own setting, if any (the context is shared and cached)
     chunk_changed = False
     sink = None
     dev_rows = c.final_rows_device(n) if (isinstance(return_final, str) and return_final == "device") else None
@@ -389,11 +459,13 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
                 # ray-splitting mode cannot bound its queue/record growth in advance: on overflow retry with smaller passes
                 if getattr(e, "code", 0) != -3 or singlechild or attempt == 7:
                     raise
-                chunk = max(256, (chunk if chunk is not None else min(n, 1 << 20)) // 4)
+                chunk = max(256, int(chunk if chunk is not None else min(n, chunk_before or (1 << 20))) // 4)
                 c.set_option("nodice_chunk", chunk); chunk_changed = True
     finally:
-        if chunk_changed:
-            c.set_option("nodice_chunk", 1 << 20)   # the smaller passes were for this call only (the context is shared and cached)
+        if chunk_changed:   # the smaller passes were for this call only: back to what the caller had set (or the library's default)
+            c.set_option("nodice_chunk", chunk_before if chunk_before is not None else (1 << 20))
+            if chunk_before is None:
+                del c.options["nodice_chunk"]
         if sink is not None:
             c.L.rt_set_record_sink(c.h, C.cast(None, _lib.RECORD_SINK), None)
         if dev_rows is not None:
@@ -407,7 +479,7 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     ray_interfaces = []
     raytable = []
     if want_rec:
-        groups = order_records(res["step"], res["ray"], res["parent"], res["flags"], ns)
+        groups = order_groups(res["step"], res["ray"], res["parent"], res["flags"], ns)
         ris = c.interfaces(groups)
         if output_raytable:  # MATLAB/RayTracer2.m:249-253, 543-548 (numpy port broken)
             raytable = np.zeros((K + 1, n, 13))
@@ -417,12 +489,12 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
             for g, ri in zip([g for g in groups if g.size], ris):
                 k = int(res["step"][g[0]])
                 cut = (res["flags"][g] & 1) == 0  # never reflected <=> positive ray_index
-                ix = res["ray"][g][cut] - ray_id_base
+                ix = (res["ray"][g][cut] - ray_id_base) // max(int(ray_id_stride), 1)
                 raytable[k + 1, ix, 0:3] = ri.intersection_point[cut]
                 raytable[k + 1, ix, 3:13] = ri.refracted_ray[cut]
         if full_output:
             ray_interfaces = ris
-    out = [np.array(ray_interfaces, dtype=object), res["table"], raytable]
+    out = [np.array(ray_interfaces, dtype=object), c.table_device(K) if device_table else res["table"], raytable]
     if return_final:
         out.append(res["final"])
     return out

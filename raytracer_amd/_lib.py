@@ -13,15 +13,15 @@ COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
 NOALLOC_MAX_RAYS, NOALLOC_MAX_SCATTERS = 262144, 4094
 
 EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device", "rt_trace_device_noalloc",
-           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_generate_camera_rays", "rt_set_record_sink", "rt_set_final_rows_device", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_table",
-           "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_record_fields", "rt_split_record_fields", "rt_result_final", "rt_result_timing",
+           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_trace_camera_range", "rt_generate_camera_rays", "rt_result_table_device", "rt_set_record_sink", "rt_set_final_rows_device", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_table",
+           "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_record_fields", "rt_split_record_fields", "rt_normalize_rays", "rt_order_records", "rt_result_final", "rt_result_timing",
            "rt_result_timing_by_kernel", "rt_device_info")
 
 
 class Params(C.Structure):
     _fields_ = [("max_scatters", C.c_int32), ("flags", C.c_int32), ("compat", C.c_int32), ("unified_maxiter", C.c_int32),
                 ("min_travel_length", C.c_double), ("follow_threshold", C.c_double * 2), ("tir_handling", C.c_double),
-                ("seed", C.c_uint64), ("ray_id_base", C.c_int64)]
+                ("seed", C.c_uint64), ("ray_id_base", C.c_int64), ("ray_id_stride", C.c_int64)]
 
 
 class Camera(C.Structure):
@@ -72,6 +72,12 @@ def load():
     L.rt_trace_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, P(Params)]
     L.rt_generate_point_source.argtypes = [C.c_void_p, P(C.c_double), C.c_int64, C.c_uint64, C.c_int64, P(C.c_double), P(C.c_double)]
     L.rt_trace_camera.argtypes = [C.c_void_p, P(Camera), P(Params)]
+    try:
+        L.rt_trace_camera_range.argtypes = [C.c_void_p, P(Camera), C.c_int64, C.c_int64, P(Params)]
+        L.rt_result_table_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    except AttributeError:
+        if "RT_LIB" not in os.environ:   # (an older A/B build named by RT_LIB may lack the newest entry points; the product's own library may not)
+            raise
     L.rt_generate_camera_rays.argtypes = [C.c_void_p, P(Camera), C.c_int64, C.c_int64, P(C.c_double), P(C.c_double), P(C.c_int32)]
     L.rt_set_record_sink.argtypes = [C.c_void_p, RECORD_SINK, C.c_void_p]
     L.rt_match_endpoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, P(C.c_int32), C.c_int32, P(MatchParams),
@@ -85,6 +91,12 @@ def load():
     L.rt_result_records.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int32), P(C.c_int64), P(C.c_int64), P(C.c_int32)]
     L.rt_result_record_fields.argtypes = [C.c_void_p, P(C.c_int64), C.c_int64, C.c_int32, P(C.c_int32), P(C.c_int32), P(P(C.c_double))]
     L.rt_split_record_fields.argtypes = [P(C.c_double), C.c_int64, P(C.c_int64), C.c_int64, C.c_int32, P(C.c_int32), P(C.c_int32), P(P(C.c_double))]
+    try:
+        L.rt_normalize_rays.argtypes = [P(C.c_double), C.c_int64]
+        L.rt_order_records.argtypes = [P(C.c_int32), P(C.c_int64), P(C.c_int64), P(C.c_int32), C.c_int64, C.c_int32, P(C.c_int64), P(C.c_int64)]
+    except AttributeError:
+        if "RT_LIB" not in os.environ:
+            raise
     L.rt_result_final.argtypes = [C.c_void_p, P(C.c_double)]
     L.rt_result_timing.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int32)]
     L.rt_result_timing_by_kernel.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int32)]

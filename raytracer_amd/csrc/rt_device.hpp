@@ -84,8 +84,17 @@ __device__ __noinline__ SinCos rt_sincos_call(double x) { // out of line: ten po
     return SinCos{ (q & 1) ? ((q & 2) ? -c : c) : ((q & 2) ? -s : s), (q & 1) ? ((q & 2) ? s : -s) : ((q & 2) ? -c : c) };
 }
 RT_HD void rt_sincos(double x, double* sn, double* cs) { const SinCos r = rt_sincos_call(x); *sn = r.s; *cs = r.c; }
+#ifdef RT_INLINE_LOGEXP
+// in line, fenced: the scheduler may not move anything across the fences, so the dozen temporaries of the polynomial live
+// only between them.  (Out of line costs more than the call: a function waits for every memory operation of its caller at
+// its entry - s_waitcnt vmcnt(0) lgkmcnt(0), the compiler cannot know what is in flight - and the software-pipelined physics
+// loop has the next ray's rows in flight right there.)
+__device__ __forceinline__ double rt_log(double x) { __builtin_amdgcn_sched_barrier(0); const double r = log(x); __builtin_amdgcn_sched_barrier(0); return r; }
+__device__ __forceinline__ double rt_exp(double x) { __builtin_amdgcn_sched_barrier(0); const double r = exp(x); __builtin_amdgcn_sched_barrier(0); return r; }
+#else
 __device__ __noinline__ double rt_log(double x) { return log(x); } // the library's, out of line for the same reason
 __device__ __noinline__ double rt_exp(double x) { return exp(x); }
+#endif
 __device__ __noinline__ double rt_cbrt(double x) { return cbrt(x); }
 #else
 RT_HD double rt_rsqrt(double x) { return 1.0 / sqrt(x); }
@@ -1141,6 +1150,10 @@ RT_HOST static inline void build_program(const double* table, int S, const doubl
                 if (below.size() < 2) { for (int j : below) used[j] = 0; below.clear(); }
             }
             for (size_t j = 0; j < mem.size(); j++) if (!used[j]) core.push_back((int)j);
+            // Tori last among the core members: a torus is only *queued* where its record stands, with a window of ray parameters
+            // that ends at the best hit so far - behind the other members that window is at its shortest, and fewer rays queue a
+            // quartic at all.  (The order of the records decides nothing else: ties go by surface number, root_wins().)
+            if (getenv("RT_TORI_IN_PLACE") == nullptr) std::stable_partition(core.begin(), core.end(), [&](int j) { return ((uint32_t)mem[j].meta & 15u) != PK_TORUS; });
             for (int j : core) { put(mem[j].meta, mem[j].w, PREC - 1); nmem++; }
             // kind 0: shell (key = r2min, ascending), 1: above (key = lo, ascending), 2: below (key = hi, descending)
             auto chain = [&](std::vector<int>& g, int kind) {
@@ -1749,8 +1762,11 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
     Rng g; rng_init(g, P.key0, P.key1, q.ray_id, q.hash, q.k);
     b.inc_intensity = q.r.s0;
     b.scat = 0; b.surf_sc = 0; b.fa = 0; b.smix_next = 0; b.six_next = 0; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = 0;
-    if (h.surf < 0) return; // RayTracer2.py:404
-    const double* row = G.surf + h.surf * ROW;
+    // RayTracer2.py:404: no surface ahead, nothing happens.  UNI = 1 keeps such a lane (and one without a ray, !act) in step with
+    // its wave - unified_wave() below needs all 64 - on the first surface's row, and takes its result back at the end.
+    const bool nohit = h.surf < 0;
+    if constexpr (UNI != 1) { if (nohit) return; }
+    const double* row = G.surf + (nohit ? 0 : h.surf) * ROW;
     const int st = (int)row[1];
     const bool in = h.orient < 0; // RayTracer2.py:351-358
     const double n1 = in ? row[16] : row[15], n2 = in ? row[15] : row[16], absl1 = in ? row[19] : row[18], rayl1 = in ? row[21] : row[20];
@@ -1789,7 +1805,7 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
     UnifiedOut uw;
     if constexpr (UNI == 1) { // all 64 lanes are here (see k_level_phys PASS 2); those with uni_sc are the rays
         const double c1 = row[24], c2 = c1 + row[25], c3 = c2 + row[26];
-        uw = unified_wave(uni_sc && act, g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
+        uw = unified_wave(uni_sc && act && !nohit, g, inc, nmech, n1, n2, row[22], row[23], c1, c2, c3, P.maxiter);
     }
 #endif
     if (nor_sc) { // :438-439
@@ -1846,6 +1862,7 @@ template <int UNI = 0, int NORAY = 0> RT_HD void bounce_phys_single(const Geom& 
     b.child = ch; b.s0_child = tot;
     b.surf_abs = inc.s0 - tot; // :471
     b.fa = tot > P.thrA; // :518
+    if constexpr (UNI == 1) { if (nohit) { b.scat = 0; b.surf_sc = 0; b.fa = 0; b.smix_next = 0; b.six_next = 0; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = 0; } }
 }
 RT_HD RayState lean_child(const RayState& q, const LeanBounce& b) { // child_of(q, b, false, true)
     RayState c;

@@ -54,6 +54,7 @@ struct KArgs {
     int mode;               // 0: initial rays, SoA in_d[f*in_stride+i]; 1: queue of spawned rays; 2: point source, 3: camera rays generated in-kernel
     const double* in_d; const int64_t* in_i; const int32_t* in_m; int64_t in_stride; int64_t n_in;
     int64_t ray_id_base;    // id of ray 0 of this launch's input (modes 0, 2)
+    int64_t id_stride;      // id of input ray i = ray_id_base + i * id_stride (1; rt_params.ray_id_stride: interleaved shards)
     int64_t slot_base;      // final-row index = ray_id - slot_base
     double ox, oy, oz;      // point source
     const double* cam; int64_t cam_base; // mode 3: camera block (see rt_trace_camera), ray id of pixel 0
@@ -89,6 +90,7 @@ struct KArgs {
     // rays that scatter in the bulk go there too, listed from the other end (defer[(b + 1) * seg_cap - 1 - j], j < defer_n[2 b + 1])
     uint32_t* defer; uint32_t* defer_n;
     uint32_t* dense;        // pass 1: the other rays of the segment, listed the same way, so that its waves are full
+    int lean;               // the level queues hold lean rows (tally-only single-child runs): set by the host, for writers and readers alike
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -142,6 +144,8 @@ __device__ __forceinline__ void gen_camera_ray(const double* cam, int64_t pix, V
     r.s0 = cam[32]; r.s1 = cam[33]; r.s2 = cam[34]; r.s3 = cam[35];
 }
 
+// row of the final-row table that belongs to ray id (rows are in input order)
+__device__ __forceinline__ int64_t fin_slot(const KArgs& a, int64_t ray_id) { const int64_t o = ray_id - a.slot_base; return a.id_stride == 1 ? o : o / a.id_stride; }
 __device__ __forceinline__ void load_queue_ray(const KArgs& a, int64_t idx, RayState& q) {
     const double* d = a.in_d; const int64_t st = a.in_stride;
     q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
@@ -153,7 +157,7 @@ __device__ __forceinline__ void load_queue_ray(const KArgs& a, int64_t idx, RayS
 }
 __device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& q, bool wantfin) {
     if (a.mode == 1) { load_queue_ray(a, idx, q); return; }
-    q.ray_id = a.ray_id_base + idx; q.parent = -1; q.hash = 0; q.k = 0; q.smix_last = 1; q.six_last = 0; q.flags = RF_PRIMARY; // RayTracer2.py:258-262
+    q.ray_id = a.ray_id_base + idx * a.id_stride; q.parent = -1; q.hash = 0; q.k = 0; q.smix_last = 1; q.six_last = 0; q.flags = RF_PRIMARY; // RayTracer2.py:258-262
     if (a.mode == 2) gen_point_ray(a, q.ray_id, q.p, q.r);
     else if (a.mode == 3) {
         gen_camera_ray(a.cam, q.ray_id - a.cam_base, q.p, q.r);
@@ -166,7 +170,7 @@ __device__ __forceinline__ void load_ray(const KArgs& a, int64_t idx, RayState& 
         q.r.s0 = d[9 * st + idx]; q.r.s1 = d[10 * st + idx]; q.r.s2 = d[11 * st + idx]; q.r.s3 = d[12 * st + idx];
     }
     if (wantfin) { // row of a ray that never interacts
-        double* f = a.fin + (q.ray_id - a.slot_base) * FIN;
+        double* f = a.fin + fin_slot(a, q.ray_id) * FIN;
         f[0] = q.p.x; f[1] = q.p.y; f[2] = q.p.z;
         put_ray10(f, 1, 3, q.r);
 #pragma unroll
@@ -185,20 +189,24 @@ __device__ __forceinline__ void store_ray(const Queue& Q, int64_t idx, const Ray
     Q.m[idx] = (int32_t)c.hash; Q.m[st + idx] = c.k; Q.m[2 * st + idx] = c.smix_last; Q.m[3 * st + idx] = c.six_last; Q.m[4 * st + idx] = c.flags;
 }
 
-// tally-only single-child runs (the level kernels' lean step): parent slot and flags mean nothing there (every ray is its own
-// primary and never marked reflected) and the step is a kernel argument, so the queue record is 124 bytes instead of 140
-// 11 doubles (below), the ray id as a 32-bit offset from the first ray of the pass, and one word for the two surface
-// indices (bits 0-23 |smix_last|, 31 its sign, 30: six_last is 0 - after a scatter in the bulk and for initial rays - and
-// not |smix_last|) and the two vector codes (bits 24-26, 27-29): 96 bytes.  The path hash is not
-// stored: with one child per interaction it is the same for every ray of a step (KArgs::lean_hash).
+// Tally-only single-child runs (the level kernels' lean step) keep a 96-byte queue record: parent slot and flags mean
+// nothing there (every ray is its own primary and never marked reflected), the step is a kernel argument, and the path
+// hash is the same for every ray of a step (one child per interaction: KArgs::lean_hash).  The record is ONE ROW of six
+// 16-byte pieces in the queue's `d` array (row i at byte 96 i):
+//   piece 0 (p.x, p.y)  1 (p.z, d.a)  2 (d.b, {ray id - first id of the pass : 32 | word : 32})  3 (pol.a, pol.b)  4 (s0, s1)  5 (s2, s3)
+// word: bits 0-23 |smix_last|, 31 its sign, 30: six_last is 0 - after a scatter in the bulk and for initial rays - and not
+// |smix_last|; bits 24-26 / 27-29 the codes of the two unit vectors (below).  Pieces 0-2 are all the nearest-hit kernel reads.
+// Rows instead of planes (round 3): a ray picked through a sparse list costs the 64-byte sectors its row touches (128 B),
+// whatever the list's density - with eleven planes of doubles a launch that took one ray in four read 4.3 times its bytes.
 __device__ __forceinline__ int32_t lean_pack(int smix, int six) { return (int32_t)((uint32_t)(smix < 0 ? -smix : smix) | (smix < 0 ? 0x80000000u : 0u) | (six == 0 ? 0x40000000u : 0u)); }
 __device__ __forceinline__ int lean_smix(int32_t w) { const int m = (int)((uint32_t)w & 0xFFFFFFu); return w < 0 ? -m : m; }
 __device__ __forceinline__ int lean_six(int32_t w) { return ((uint32_t)w & 0x40000000u) ? 0 : (int)((uint32_t)w & 0xFFFFFFu); }
 // Direction and polarisation reference are unit vectors: two components travel, the largest one is rebuilt from them
 // (error ~1e-16).  Code: bits 0-1 which component is left out, bit 2 its sign; 3 = the vector is not a unit vector (zero: a
-// polarisation reference along the direction; NaN) and goes as (x, y, 0).
-constexpr int LQD = 11; // doubles of a lean record: p(3) d(2) pol(2) s0..s3
-__device__ __forceinline__ uint32_t uv_pack(V3 v, double& a_, double& b_) {
+// polarisation reference along the direction; NaN) and goes as (x, y, 0).  `lossy`: a finite vector that is not unit and has
+// a z component - nothing the kernels hand on is one (every producer normalises); the caller reports it (overflow code 3)
+// instead of dropping the component in silence.
+__device__ __forceinline__ uint32_t uv_pack(V3 v, double& a_, double& b_, bool& lossy) {
     const double ax = fabs(v.x), ay = fabs(v.y), az = fabs(v.z);
     const uint32_t j = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
     const double n2 = v.x * v.x + v.y * v.y + v.z * v.z;
@@ -206,6 +214,7 @@ __device__ __forceinline__ uint32_t uv_pack(V3 v, double& a_, double& b_) {
     const double vj = j == 0u ? v.x : (j == 1u ? v.y : v.z);
     a_ = unit ? (j == 0u ? v.y : (j == 1u ? v.z : v.x)) : v.x;
     b_ = unit ? (j == 0u ? v.z : (j == 1u ? v.x : v.y)) : v.y;
+    lossy = lossy | (!unit & (n2 < INFINITY) & (v.z != 0.0));
     return unit ? (j | (vj < 0 ? 4u : 0u)) : 3u;
 }
 __device__ __forceinline__ V3 uv_unpack(uint32_t code, double a_, double b_) {
@@ -215,25 +224,53 @@ __device__ __forceinline__ V3 uv_unpack(uint32_t code, double a_, double b_) {
     if (j == 3u) return V3{ a_, b_, 0.0 };
     return j == 0u ? V3{ w, a_, b_ } : (j == 1u ? V3{ b_, w, a_ } : V3{ a_, b_, w });
 }
-__device__ __forceinline__ void store_ray_lean(const Queue& Q, int64_t idx, const RayState& c, int64_t id_base) {
-    double* d = Q.d; const int64_t st = Q.cap;
+typedef double __attribute__((ext_vector_type(2))) d2;
+constexpr int LROW = 6;                 // 16-byte pieces of a lean row
+struct LeanRow { d2 v[LROW]; };
+// rid: the ray's number within the pass (its id = first id of the pass + rid * stride); a child takes its parent's as it is
+__device__ __forceinline__ LeanRow lean_row_pack(const RayState& c, uint32_t rid, bool& lossy) {
     double da, db, pa, pb;
-    const uint32_t cd = uv_pack(c.r.d, da, db), cp = uv_pack(c.r.pol, pa, pb);
-    d[0 * st + idx] = c.p.x; d[1 * st + idx] = c.p.y; d[2 * st + idx] = c.p.z;
-    d[3 * st + idx] = da; d[4 * st + idx] = db; d[5 * st + idx] = pa; d[6 * st + idx] = pb;
-    d[7 * st + idx] = c.r.s0; d[8 * st + idx] = c.r.s1; d[9 * st + idx] = c.r.s2; d[10 * st + idx] = c.r.s3;
-    Q.m[idx] = (int32_t)(c.ray_id - id_base); Q.m[2 * st + idx] = lean_pack(c.smix_last, c.six_last) | (int32_t)((cd << 24) | (cp << 27));
+    const uint32_t cd = uv_pack(c.r.d, da, db, lossy), cp = uv_pack(c.r.pol, pa, pb, lossy);
+    const uint32_t w = (uint32_t)lean_pack(c.smix_last, c.six_last) | (cd << 24) | (cp << 27);
+    LeanRow r;
+    r.v[0] = d2{ c.p.x, c.p.y }; r.v[1] = d2{ c.p.z, da }; r.v[2] = d2{ db, __longlong_as_double((long long)(((unsigned long long)w << 32) | rid)) };
+    r.v[3] = d2{ pa, pb }; r.v[4] = d2{ c.r.s0, c.r.s1 }; r.v[5] = d2{ c.r.s2, c.r.s3 };
+    return r;
 }
-__device__ __forceinline__ void load_queue_ray_lean(const KArgs& a, int64_t idx, RayState& q) {
-    const double* d = a.in_d; const int64_t st = a.in_stride;
-    const int32_t w = a.in_m[2 * st + idx];
-    q.p = V3{ d[0 * st + idx], d[1 * st + idx], d[2 * st + idx] };
-    q.r.d = uv_unpack(((uint32_t)w >> 24) & 7u, d[3 * st + idx], d[4 * st + idx]);
-    q.r.pol = uv_unpack(((uint32_t)w >> 27) & 7u, d[5 * st + idx], d[6 * st + idx]);
-    q.r.s0 = d[7 * st + idx]; q.r.s1 = d[8 * st + idx]; q.r.s2 = d[9 * st + idx]; q.r.s3 = d[10 * st + idx];
-    q.ray_id = a.slot_base + (int64_t)a.in_m[idx]; q.parent = -1; q.hash = a.lean_hash; q.k = a.step; q.smix_last = lean_smix(w); q.six_last = lean_six(w); q.flags = RF_PRIMARY;
+__device__ __forceinline__ uint32_t lean_row_rid(const LeanRow& r) { return (uint32_t)(unsigned long long)__double_as_longlong(r.v[2].y); }
+__device__ __forceinline__ int32_t lean_row_word(const LeanRow& r) { return (int32_t)((unsigned long long)__double_as_longlong(r.v[2].y) >> 32); }
+__device__ __forceinline__ void lean_row_unpack(const LeanRow& r, const KArgs& a, RayState& q) {
+    const int32_t w = lean_row_word(r); const uint32_t rid = lean_row_rid(r);
+    q.p = V3{ r.v[0].x, r.v[0].y, r.v[1].x };
+    q.r.d = uv_unpack(((uint32_t)w >> 24) & 7u, r.v[1].y, r.v[2].x);
+    q.r.pol = uv_unpack(((uint32_t)w >> 27) & 7u, r.v[3].x, r.v[3].y);
+    q.r.s0 = r.v[4].x; q.r.s1 = r.v[4].y; q.r.s2 = r.v[5].x; q.r.s3 = r.v[5].y;
+    q.ray_id = a.slot_base + (int64_t)rid * a.id_stride; q.parent = -1; q.hash = a.lean_hash; q.k = a.step; q.smix_last = lean_smix(w); q.six_last = lean_six(w); q.flags = RF_PRIMARY;
+}
+// A lane moves its own row: six 16-byte loads or stores at a stride of 96 bytes between lanes.  Measured against moving
+// rows with the whole wave (six lanes per row, whole rows per instruction, an LDS tile to turn pieces into one row per lane;
+// also with the incoming pieces sent straight to LDS, global_load_lds_dwordx4): as a pure copy the wave-wide way streams 13 %
+// faster (tools/mb_queue.hip) - but these launches are not bound by how their bytes move (profiles/r3_layout_experiment.txt:
+// half the bytes, the same cycles), and beside the other lane's nearest-hit launch the LDS traffic of the transposition
+// cost both kernels 2-3 %.
+__device__ __forceinline__ void row_load(const d2* rows, int64_t idx, LeanRow& r) {
+#pragma unroll
+    for (int f = 0; f < LROW; f++) r.v[f] = rows[idx * LROW + f];
+}
+__device__ __forceinline__ void row_store(d2* rows, int64_t idx, const LeanRow& r) {
+#pragma unroll
+    for (int f = 0; f < LROW; f++) rows[idx * LROW + f] = r.v[f];
 }
 
+__device__ __forceinline__ void store_ray_lean(const Queue& Q, int64_t idx, const RayState& c, uint32_t rid, int* overflow) {
+    bool lossy = false; const LeanRow r = lean_row_pack(c, rid, lossy);
+    row_store((d2*)Q.d, idx, r);
+    if (lossy) *overflow = 3;
+}
+__device__ __forceinline__ void load_queue_ray_lean(const KArgs& a, int64_t idx, RayState& q) {
+    LeanRow r; row_load((const d2*)a.in_d, idx, r);
+    lean_row_unpack(r, a, q);
+}
 // slot allocation for the lanes that are active here: one atomic per wave, consecutive slots in lane order
 __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* counter) {
     unsigned long long act = __ballot(1);
@@ -293,9 +330,17 @@ namespace {
 #ifndef RT_WAVES
 #define RT_WAVES 4
 #endif
+#ifndef RT_LEAN_TRACE_WAVES
+#define RT_LEAN_TRACE_WAVES 2
+#endif
 // CF: flag set this instance is compiled for (FLAG_SINGLE exact; FLAG_FULL/FLAG_FINAL = "may be requested", 0 = never)
 // LEAN: tally-only single-child step (bounce_phys_single); GEN: the program has surfaces outside every frame
-template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_bounds__(BLOCK, RT_WAVES) k_trace(const KArgs a) {
+// UNI (LEAN only): 1 = the geometry has UNIFIED surfaces, 2 = it has none (no such code).  The lean instances are what small
+// runs and the tails of large ones are traced by, where a wave's time per bounce is all that counts: they take the whole
+// register file (2 waves per SIMD), the nearest-hit search in line, and with UNI = 1 the wave draws its facet normals together
+// (unified_wave: every lane goes through the step, `alive` marks the rays) - out of line under a 128-register budget, with the
+// rough-surface loop run lane by lane, a bounce took a wave 69 us (round 2: 251 spilled VGPRs), three times what it takes now.
+template <int CF, bool LEAN = false, bool GEN = true, int UNI = 0> __global__ void __launch_bounds__(BLOCK, LEAN ? RT_LEAN_TRACE_WAVES : RT_WAVES) k_trace(const KArgs a) {
     extern __shared__ double smem[];
     // LDS image: surface rows (per-lane gather of the winning surface) | tally rows | per-step counters
     double* s_surf = smem + HDR_DOUBLES + TQ_DOUBLES;
@@ -317,6 +362,7 @@ template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_b
     const Prm P = a.P;
     const int lane = lane_id();
     RayState q;
+    if constexpr (LEAN) { q.p = V3{ 0, 0, 0 }; q.r.d = V3{ 0, 0, 1 }; q.r.pol = V3{ 1, 0, 0 }; q.r.s0 = q.r.s1 = q.r.s2 = q.r.s3 = 0; q.ray_id = 0; q.parent = -1; q.hash = 0; q.k = 0; q.smix_last = 1; q.six_last = 0; q.flags = 0; } // idle lanes go through the step too
     bool alive = false, more = true;
     const bool full = (CF & FLAG_FULL) && (P.flags & FLAG_FULL), wantfin = (CF & FLAG_FINAL) && (P.flags & FLAG_FINAL);
     constexpr int BF = CF & FLAG_SINGLE; // what the per-ray arithmetic needs to know
@@ -356,16 +402,17 @@ template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_b
         pt[5] += 1; pt[6] += __popcll(__ballot(alive));
 #endif
         Hit h; h.l = INFINITY; h.surf = -1; h.orient = 0;
-        if constexpr (GEN) bounce_hit(G, P, q, alive, h); // all lanes: idle ones still serve the wave's torus queue
+        if constexpr (LEAN) { q.r.d = normalized_if(q.r.d); find_hit<GEN>(G, P, q.p, q.r.d, q.six_last, alive, h); } // RayToShape.py:11-14
+        else if constexpr (GEN) bounce_hit(G, P, q, alive, h); // all lanes: idle ones still serve the wave's torus queue
         else { q.r.d = normalized_if(q.r.d); h = find_hit_ool_t<false>(q.p, q.r.d, q.six_last, alive); }
 #ifdef RT_PROFILE
         pt[4] += h.ps; pt[7] += h.pm; pt[8] += h.pc; pt[9] += h.pn; pt[10] += h.pf; pt[11] += h.pt_;
 #endif
         PROF_ADD(1)
         if constexpr (LEAN) {
+            LeanBounce b; bounce_phys_single<UNI>(G, P, q, h, b, alive); // every lane (UNI = 1: the wave works through the rough-surface loop together)
             if (alive) {
                 const int k = q.k;
-                LeanBounce b; bounce_phys_single(G, P, q, h, b);
                 atomicAdd(&s_live[k], 1u);
                 if (!b.scat) { tally_add(a, s_tab, k, 2, q.smix_last, b.inc_intensity); alive = false; } // escaped: RayTracer2.py:485-486
                 else {
@@ -403,7 +450,7 @@ template <int CF, bool LEAN = false, bool GEN = true> __global__ void __launch_b
                         myslot = (int64_t)slot;
                     } else *a.overflow = 1;
                 }
-                if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + (q.ray_id - a.slot_base) * FIN);
+                if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + fin_slot(a, q.ray_id) * FIN);
                 const bool last = (k + 1 >= P.K);
                 if (last || !(b.fa || b.fb)) alive = false;
                 else {
@@ -480,7 +527,7 @@ template <int CF> __global__ void __launch_bounds__(BLOCK) k_level_init(const KA
     RayState q; load_ray(a, idx, q, wantfin);
     q.r.d = normalized_if(q.r.d); // RayToShape.py:11-14
     const int64_t sg = idx / a.seg_fill, off = idx % a.seg_fill;
-    if (a.P.flags == FLAG_SINGLE) store_ray_lean(a.out, sg * a.seg_cap + off, q, a.slot_base); else store_ray(a.out, sg * a.seg_cap + off, q);
+    if (a.lean) store_ray_lean(a.out, sg * a.seg_cap + off, q, (uint32_t)idx, a.overflow); else store_ray(a.out, sg * a.seg_cap + off, q);
     if (off == 0) a.seg_out[sg] = (uint32_t)(a.n_in - idx < a.seg_fill ? a.n_in - idx : a.seg_fill);
 }
 // segments -> dense queue (hand-over to the persistent kernel)
@@ -491,7 +538,7 @@ __global__ void __launch_bounds__(BLOCK) k_level_compact(const KArgs a) {
     if (threadIdx.x == 0) s_base = atomicAdd(a.tail, (unsigned long long)n);
     __syncthreads();
     const int64_t ob = (int64_t)s_base;
-    const bool lean = a.P.flags == FLAG_SINGLE; // lean records (store_ray_lean) leave these out
+    const bool lean = a.lean != 0;
     for (int64_t i = threadIdx.x; i < n; i += BLOCK) {
         RayState q;
         if (lean) load_queue_ray_lean(a, base + i, q); else load_queue_ray(a, base + i, q);
@@ -521,9 +568,11 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
         V3 p = { 0, 0, 0 }, d = { 0, 0, 1 }; int six = 0;
         if (act) {
             const double* q = a.in_d;
-            p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] };
-            if (a.lean) { const int32_t w = a.in_m[2 * st + idx]; six = lean_six(w); d = normalized_if(uv_unpack(((uint32_t)w >> 24) & 7u, q[3 * st + idx], q[4 * st + idx])); }
-            else { d = normalized_if(V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] }); six = a.in_m[3 * st + idx]; } // RayToShape.py:11-14
+            if (a.lean) { // the first three pieces of the ray's row
+                const d2* row = (const d2*)q + idx * LROW; const d2 r0 = row[0], r1 = row[1], r2 = row[2];
+                const int32_t w = (int32_t)((unsigned long long)__double_as_longlong(r2.y) >> 32);
+                p = V3{ r0.x, r0.y, r1.x }; six = lean_six(w); d = normalized_if(uv_unpack(((uint32_t)w >> 24) & 7u, r1.y, r2.x));
+            } else { p = V3{ q[0 * st + idx], q[1 * st + idx], q[2 * st + idx] }; d = normalized_if(V3{ q[3 * st + idx], q[4 * st + idx], q[5 * st + idx] }); six = a.in_m[3 * st + idx]; } // RayToShape.py:11-14
         }
         Hit h;
 #ifdef RT_PROFILE
@@ -602,65 +651,56 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
         // works on next (and the list entry of the one after) is requested before the physics of the current one starts, so
         // the ~2 us an HBM round trip takes under load pass during ~1 500 vector instructions instead of in front of them.
         // (Measured on the unpipelined loop, r2d: its waves spent 55 % of their cycles in s_waitcnt at 3 waves/SIMD.)
-        struct Raw { double v[LQD]; double hl; int32_t rid, sm, so; };
-        const double* D = a.in_d; const int64_t st = a.in_stride; const int lane = lane_id();
+        struct Raw { LeanRow row; double hl; int32_t so; };
+        const d2* rows = (const d2*)a.in_d; const int lane = lane_id();
         // list entries travel as loaded (no arithmetic on them until the iteration that needs the slot: a use would make the wave wait for the load)
         auto entry_of = [&](int64_t base) -> uint32_t { const int64_t i = base + lane; return (listed && i < n) ? list[i] : 0u; };
         auto slot_of = [&](int64_t base, uint32_t e) -> int64_t { const int64_t i = base + lane; if (i >= n) return -1; return listed ? seg0 + (int64_t)e : i; };
         auto fetch = [&](int64_t idx, Raw& r) {
             if (idx < 0) return;
             r.so = a.hit_so[idx]; r.hl = a.hit_l[idx];
-#pragma unroll
-            for (int f = 0; f < LQD; f++) r.v[f] = D[f * st + idx];
-            r.rid = a.in_m[idx]; r.sm = a.in_m[2 * st + idx];
+            row_load(rows, idx, r.row);
         };
         const int64_t first = seg0 + (threadIdx.x & ~63);
         int64_t idx1 = slot_of(first, entry_of(first));
         uint32_t e2 = entry_of(first + BLOCK);
         Raw nxt = {}; fetch(idx1, nxt);
         __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), as an instruction the compiler's own wait-count pass sees (inline asm is opaque to it) */ // the loop is entered as it is re-entered: nothing in flight (or the compiler makes every iteration wait at the top for what only the first has pending)
+        d2* const out_rows = (d2*)a.out.d;
         for (int64_t base = first; base < n; base += BLOCK) {
             const Raw cur = nxt; const int64_t idx = idx1;
             idx1 = slot_of(base + BLOCK, e2);
             fetch(idx1, nxt);
-            e2 = entry_of(base + 2 * BLOCK); // behind the record's loads: the wave's memory counter is in order, and what waits for them must not wait for this
-            RayState c; int64_t at = -1;
+            e2 = entry_of(base + 2 * BLOCK); // behind the row's loads: the wave's memory counter is in order, and what waits for them must not wait for this
+            LeanRow crow; int64_t at = -1; bool lossy = false;
             if (idx >= 0) {
-                RayState q;
-                q.p = V3{ cur.v[0], cur.v[1], cur.v[2] };
-                q.r.d = normalized_if(uv_unpack(((uint32_t)cur.sm >> 24) & 7u, cur.v[3], cur.v[4])); q.r.pol = uv_unpack(((uint32_t)cur.sm >> 27) & 7u, cur.v[5], cur.v[6]);
-                q.r.s0 = cur.v[7]; q.r.s1 = cur.v[8]; q.r.s2 = cur.v[9]; q.r.s3 = cur.v[10];
-                q.ray_id = a.slot_base + (int64_t)cur.rid; q.parent = -1; q.hash = a.lean_hash; q.k = k; q.smix_last = lean_smix(cur.sm); q.six_last = lean_six(cur.sm); q.flags = RF_PRIMARY;
+                RayState q; lean_row_unpack(cur.row, a, q);
+                q.r.d = normalized_if(q.r.d);
                 Hit h; h.l = cur.hl; h.surf = cur.so < 0 ? -1 : (cur.so >> 2); h.orient = cur.so < 0 ? 0 : (cur.so & 3) - 1;
                 LeanBounce b;
-#if defined(RT_EXP) && (RT_EXP & 4)
-                b.scat = 1; b.surf_sc = 1; b.fa = 1; b.smix_next = h.surf + 1; b.six_next = h.surf + 1; b.bulk_abs = 0; b.surf_abs = 0; b.s0_child = q.r.s0; b.p = q.p + h.l * q.r.d; b.child = q.r; b.inc_intensity = q.r.s0;
-#else
                 if constexpr (PASS == 1) bounce_phys_single<2, 2>(G, P, q, h, b, true);
                 else bounce_phys_single<PASS == 3 ? 2 : 0>(G, P, q, h, b, true);
-#endif
                 if (PASS == 1 && b.scat == 2) a.defer[seg0 + a.seg_cap - 1 - (int64_t)wave_alloc_lds(&s_cnt[5])] = (uint32_t)(idx - seg0); // scatters in the bulk: the other launch's
                 else atomicAdd(&s_cnt[0], 1u);
                 if (PASS == 1 && b.scat == 2) {}
                 else if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
                 else {
                     atomicAdd(&s_cnt[1], 1u);
-#if !(defined(RT_EXP) && (RT_EXP & 1))
                     if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);
                     tally_add(t, s_tab, 0, 1, b.smix_next, b.bulk_abs);
                     tally_add(t, s_tab, 0, b.fa ? 4 : 3, b.smix_next, b.s0_child);
-#endif
-                    if (k + 1 < P.K && b.fa) { c = lean_child(q, b); at = seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]); } // at most one child per ray: the segment cannot overflow
+                    if (k + 1 < P.K && b.fa) { crow = lean_row_pack(lean_child(q, b), lean_row_rid(cur.row), lossy); at = seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]); } // at most one child per ray: the segment cannot overflow
                 }
             }
-            // The wave's memory counter counts loads and stores together, in order.  The next record's loads are older than
+            // The wave's memory counter counts loads and stores together, in order.  The next row's loads are older than
             // this child's stores only if the stores come behind the point that waits for them; placed in front, every
             // iteration would wait for its own stores to be acknowledged.  So: wait here (the loads have had the whole
             // step to land; the previous child's stores are older still), then store.
             PP_ADD(3)
             __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), as an instruction the compiler's own wait-count pass sees (inline asm is opaque to it) */
             PP_ADD(4)
-            if (at >= 0) store_ray_lean(a.out, at, c, a.slot_base);
+            if (at >= 0) row_store(out_rows, at, crow);
+            if (lossy) *a.overflow = 3;
         }
     } else
     for (int64_t base = seg0 + (threadIdx.x & ~63);; base += BLOCK) {
@@ -683,18 +723,19 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
         if (act || WAVE) {
             if (listed) idx = seg0 + (int64_t)list[idx];
             const int so = a.hit_so[idx];
-            RayState q;
-            if constexpr (CF == FLAG_SINGLE) load_queue_ray_lean(a, idx, q); else load_queue_ray(a, idx, q);
+            RayState q; uint32_t my_rid = 0;
+            if constexpr (CF == FLAG_SINGLE) { LeanRow mine; row_load((const d2*)a.in_d, idx, mine); lean_row_unpack(mine, a, q); my_rid = lean_row_rid(mine); }
+            else load_queue_ray(a, idx, q);
             q.k = k;
             q.r.d = normalized_if(q.r.d);
             Hit h; h.l = a.hit_l[idx];
             h.surf = so < 0 ? -1 : (so >> 2); h.orient = so < 0 ? 0 : (so & 3) - 1;
             if (act) atomicAdd(&s_cnt[0], 1u);
             if constexpr (CF == FLAG_SINGLE) { // tallies only: one child, built after the dice
+                static_assert(CF != FLAG_SINGLE || PASS == 2, "the tally-only step of the other passes is the pipelined loop above");
                 LeanBounce b;
-                // PASS 1 working through its list: neither UNIFIED surfaces nor bulk scatters come here (the sort above decided)
-                if constexpr (PASS == 1) bounce_phys_single<2, 1>(G, P, q, h, b, act);
-                else bounce_phys_single<PASS == 2 ? 1 : (PASS == 3 ? 2 : 0)>(G, P, q, h, b, act);
+                bounce_phys_single<1>(G, P, q, h, b, act);
+                bool lossy = false;
                 if (!act) {}
                 else if (!b.scat) tally_add(t, s_tab, 0, 2, q.smix_last, b.inc_intensity); // escaped: RayTracer2.py:485-486
                 else {
@@ -702,11 +743,10 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
                     if (b.surf_sc) tally_add(t, s_tab, 0, 0, b.smix_next, b.surf_abs);
                     tally_add(t, s_tab, 0, 1, b.smix_next, b.bulk_abs);
                     tally_add(t, s_tab, 0, b.fa ? 4 : 3, b.smix_next, b.s0_child);
-                    if (k + 1 < P.K && b.fa) {
-                        RayState c = lean_child(q, b);
-                        store_ray_lean(a.out, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), c, a.slot_base); // at most one child per ray: the segment cannot overflow
-                    }
+                    if (k + 1 < P.K && b.fa) // the child behind those of pass 1 (at most one child per ray: the segment cannot overflow)
+                        row_store((d2*)a.out.d, seg0 + (int64_t)wave_alloc_lds(&s_cnt[2]), lean_row_pack(lean_child(q, b), my_rid, lossy));
                 }
+                if (lossy) *a.overflow = 3;
             } else {
                 Bounce b; b.scat = 0;
                 bounce_phys<BF, PASS == 2 ? 1 : ((PASS == 1 || PASS == 3) ? 2 : 0)>(G, P, q, h, b);
@@ -726,7 +766,7 @@ template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS
                             myslot = (int64_t)slot;
                         } else *a.overflow = 1;
                     }
-                    if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + (q.ray_id - a.slot_base) * FIN);
+                    if (wantfin && (q.flags & RF_PRIMARY)) fill_final(q, b, P, a.fin + fin_slot(a, q.ray_id) * FIN);
                     if (k + 1 < P.K && (b.fa || b.fb)) { // single child: exactly one of fa, fb can be set
                         if constexpr (BF == 0) {
                             if (b.fa && b.fb) { // split (python/RayTracer2.py:531-540): the reflected child as well
@@ -833,6 +873,7 @@ struct rt_ctx {
     // geometry
     double* d_surf = nullptr; double* d_recs = nullptr; uint32_t* d_smeta = nullptr; double* d_lut = nullptr;
     double* d_cam = nullptr; // camera block of the last rt_trace_camera / rt_generate_camera_rays
+    int64_t cam_first = 0;   // rt_trace_camera_range: pixel of the call's first ray
     double* d_prog = nullptr; int nprog_frames = 0, nprog_generic = 0; // frame program, then the all-generic program
     bool use_frames = true, frames_have_generic = false;
     bool has_rayleigh = false, has_unified = false; bool defer_unified = true;
@@ -840,6 +881,7 @@ struct rt_ctx {
     // persistent small buffers
     unsigned long long* d_counters = nullptr; // head, tail, rec_count + overflow(int)
     double* d_table = nullptr; size_t table_elems = 0; unsigned long long* d_steps = nullptr; int steps_K = 0;
+    double* d_table_ext = nullptr; unsigned long long* d_steps_ext = nullptr; // a lane of run_trace_lanes tallies into its parent's table and counters (cleared by the parent)
     // results of the last trace
     int K = 0; int num_steps = 0; int64_t n_rays = 0;
     std::vector<double> table; std::vector<int64_t> n_live, n_scat;
@@ -864,10 +906,10 @@ struct rt_ctx {
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 1 << 20; int64_t level_min_rays = 1 << 15; int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, hit_split_lanes = 12, seg_per_cu = 8; bool seg_auto = true; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
+    int level_steps = 1 << 20; int64_t level_min_rays = 3 << 18; /* 786 432: below, the persistent kernel is faster (profiles/r3_sweep.json) */ int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, hit_split_lanes = 12, seg_per_cu = 8; bool seg_auto = true; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
-    // second lane of large tally-only runs (run_trace_lanes): a context of its own that borrows this one's geometry
-    // (off by default: the launches of two lanes overlap, which is what it is for, and per-kernel times then mean little)
+    // further lanes of large tally-only runs (run_trace_lanes; two by default): contexts of their own that borrow this one's
+    // geometry.  The launches of the lanes overlap - which is what they are for - so per-kernel times then include the company
     int lanes = 2; int64_t lanes_min_rays = (int64_t)1 << 21; rt_ctx* lane[3] = { nullptr, nullptr, nullptr }; bool is_lane = false, raw_tally = false;
     // the lanes take turns with the nearest-hit launch (run_trace_lanes): what each has recorded so far, and the events
     struct LanePair { int L; std::atomic<int> rec[4]; std::atomic<int> done[4]; hipEvent_t ev[4][8]; }* pair = nullptr;
@@ -884,7 +926,9 @@ constexpr int MAX_BATCH = 16; // level steps launched between two host synchroni
 static unsigned char* g_scratch_ptr[MAX_DEVICES];
 static std::mutex g_scratch_mutex;
 
-static std::string g_init_err;
+// rt_init has no context to leave its message in: rt_last_error(NULL) returns the message of the calling thread's last
+// failed rt_init (one context per (GPU, host thread) is the header's contract, so threads may call rt_init side by side)
+static thread_local std::string g_init_err;
 #define CK(call)                                                                                                           \
     do {                                                                                                                   \
         hipError_t e_ = (call);                                                                                            \
@@ -1024,13 +1068,6 @@ extern "C" int rt_set_surfaces(rt_ctx* ctx, const double* table, int32_t n_surf,
     build_program(table, n_surf, atoms, code, true, recs, smeta, prog);
     build_program(table, n_surf, atoms, code, false, recs, smeta, prog_generic);
     finish_device_tables(recs);
-#ifdef RT_EXPERIMENTS
-    if (const char* sk = getenv("RT_DEBUG_SKIP_KINDS")) { // timing experiments only (results are wrong): drop program records by kind
-        const unsigned mask = (unsigned)atoi(sk); std::vector<double> kept;
-        for (size_t i = 0; i + PREC <= prog.size(); i += PREC) { uint64_t m; memcpy(&m, &prog[i], 8); if (i + PREC == prog.size() || !((mask >> (m & 15u)) & 1u)) kept.insert(kept.end(), prog.begin() + i, prog.begin() + i + PREC); }
-        prog.swap(kept);
-    }
-#endif
     ctx->frames_have_generic = false;
     for (size_t i = 0; i + PREC < prog.size(); i += PREC) { uint64_t m; memcpy(&m, &prog[i], 8); if ((m & 15u) == PK_GENERIC) ctx->frames_have_generic = true; }
     ctx->nprog_frames = (int)(prog.size() / PREC) - 1; ctx->nprog_generic = (int)(prog_generic.size() / PREC) - 1;
@@ -1095,8 +1132,36 @@ int alloc_queue(rt_ctx* ctx, Queue& q, DevBuf& bd, DevBuf& bi, DevBuf& bm, int64
     return 0;
 }
 
+// dynamic LDS of k_level_phys: surface rows | the step's tally row | 8 counters
+static size_t lds_phys_bytes(int S) { return (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 32; }
+
 // path hash of every ray of step k when each interaction leaves one child (lean_child(): path_hash(h, k, 0) from h = 0)
 static uint32_t lean_hash_of(int k) { uint32_t h = 0; for (int j = 0; j < k; j++) h = path_hash(h, j, 0); return h; }
+
+// absorption_table [K][5][S][2] and the per-step counters [2][K] of a trace on the device: room for K steps, cleared
+int prepare_tallies(rt_ctx* ctx, int K) {
+    const size_t telems = (size_t)K * 5 * ctx->S * 2;
+    if (ctx->table_elems < telems) { hipFree(ctx->d_table); ctx->d_table = nullptr; ctx->table_elems = 0; CK(hipMalloc(&ctx->d_table, telems * 8)); ctx->table_elems = telems; }
+    if (ctx->steps_K < K) { hipFree(ctx->d_steps); ctx->d_steps = nullptr; ctx->steps_K = 0; CK(hipMalloc(&ctx->d_steps, sizeof(unsigned long long) * 2 * (size_t)K)); ctx->steps_K = K; }
+    CK(hipMemsetAsync(ctx->d_table, 0, telems * 8, ctx->stream));
+    CK(hipMemsetAsync(ctx->d_steps, 0, sizeof(unsigned long long) * 2 * (size_t)K, ctx->stream));
+    return 0;
+}
+// ... to the host, with the reference's step bookkeeping (RayTracer2.py:266-270, 405-407, 542)
+int fetch_tallies(rt_ctx* ctx, int K) {
+    const int S = ctx->S; const size_t telems = (size_t)K * 5 * S * 2;
+    ctx->table.assign(telems, 0.0); std::vector<unsigned long long> st(2 * (size_t)K);
+    CK(hipMemcpyAsync(ctx->table.data(), ctx->d_table, telems * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(st.data(), ctx->d_steps, sizeof(unsigned long long) * 2 * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->n_live.assign(K, 0); ctx->n_scat.assign(K, 0);
+    int ns = 0;
+    for (int k = 0; k < K; k++) { ctx->n_live[k] = (int64_t)st[k]; ctx->n_scat[k] = (int64_t)st[K + k]; if (st[k] > 0) ns = k + 1; }
+    for (int k = 0; k < ns; k++)
+        if (ctx->n_scat[k] == 0) std::fill(ctx->table.begin() + (size_t)k * 5 * S * 2, ctx->table.begin() + (size_t)(k + 1) * 5 * S * 2, 0.0); // `continue` before the tallies
+    ctx->num_steps = ns;
+    return 0;
+}
 
 // mode 0: h_start/h_rays host arrays or d_soa device SoA; mode 2: point source
 int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm, int64_t soa_stride = 0) {
@@ -1104,6 +1169,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     if (n <= 0) { ctx->err = "Improper input to RayTracer2"; return -1; }
     const int K = prm->max_scatters;
     if (K < 1 || K > 4094) { ctx->err = "rt_trace: max_scatters must be in 1..4094"; return -1; }
+    if (prm->flags & ~(RT_FLAG_FULL_OUTPUT | RT_FLAG_SINGLECHILD | RT_FLAG_FINAL_ROWS)) { ctx->err = "rt_trace: unknown bits in rt_params.flags"; return -1; }
+    if (prm->compat & ~(RT_COMPAT_PY_INDEX | RT_COMPAT_PY_ROOT2)) { ctx->err = "rt_trace: unknown bits in rt_params.compat"; return -1; }
     CK(hipSetDevice(ctx->device));
     const int S = ctx->S;
     const bool full = prm->flags & RT_FLAG_FULL_OUTPUT, single = prm->flags & RT_FLAG_SINGLECHILD, wantfin = prm->flags & RT_FLAG_FINAL_ROWS;
@@ -1112,10 +1179,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 
     // ---- per-call device state
     size_t telems = (size_t)K * 5 * S * 2;
-    if (ctx->table_elems < telems) { hipFree(ctx->d_table); ctx->d_table = nullptr; CK(hipMalloc(&ctx->d_table, telems * 8)); ctx->table_elems = telems; }
-    if (ctx->steps_K < K) { hipFree(ctx->d_steps); ctx->d_steps = nullptr; CK(hipMalloc(&ctx->d_steps, sizeof(unsigned long long) * 2 * (size_t)K)); ctx->steps_K = K; }
-    CK(hipMemsetAsync(ctx->d_table, 0, telems * 8, ctx->stream));
-    CK(hipMemsetAsync(ctx->d_steps, 0, sizeof(unsigned long long) * 2 * (size_t)K, ctx->stream));
+    if (!ctx->d_table_ext && prepare_tallies(ctx, K)) return -1; // (a lane: its parent has done this before the lanes started)
+    double* const d_table = ctx->d_table_ext ? ctx->d_table_ext : ctx->d_table; unsigned long long* const d_steps = ctx->d_table_ext ? ctx->d_steps_ext : ctx->d_steps;
     ctx->K = K; ctx->n_rays = n; ctx->kernel_ms = 0; ctx->n_launches = 0;
     for (int i = 0; i < 3; i++) { ctx->ms_kind[i] = 0; ctx->n_kind[i] = 0; }
     // level-synchronous path: single-child runs with at most one child per ray and step
@@ -1138,7 +1203,10 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     const bool out = full || wantfin;
     void (*kern)(const KArgs) = single ? (out ? k_trace<FLAG_SINGLE | FLAG_FULL | FLAG_FINAL> : k_trace<FLAG_SINGLE>) : (out ? k_trace<FLAG_FULL | FLAG_FINAL> : k_trace<0>);
     const bool frames_only = ctx->use_frames && !(prm->compat & RT_COMPAT_PY_ROOT2) && !ctx->frames_have_generic;
-    if (single && !out && !(prm->follow_threshold[1] < 0)) kern = frames_only ? k_trace<FLAG_SINGLE, true, false> : k_trace<FLAG_SINGLE, true, true>;
+    if (single && !out && !(prm->follow_threshold[1] < 0)) {
+        if (ctx->has_unified) kern = frames_only ? k_trace<FLAG_SINGLE, true, false, 1> : k_trace<FLAG_SINGLE, true, true, 1>;
+        else kern = frames_only ? k_trace<FLAG_SINGLE, true, false, 2> : k_trace<FLAG_SINGLE, true, true, 2>;
+    }
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int bpc = ctx->blocks_per_cu;
     if (bpc <= 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, lds) != hipSuccess || nb < 1) nb = 1; bpc = nb > 8 ? 8 : nb; }
@@ -1245,12 +1313,14 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     a.P.K = K; a.P.flags = prm->flags; a.P.compat = prm->compat; a.P.maxiter = prm->unified_maxiter > 0 ? prm->unified_maxiter : 10000;
     a.P.base = (prm->compat & RT_COMPAT_PY_INDEX) ? 0 : 1; a.P.min_travel = prm->min_travel_length; a.P.thrA = prm->follow_threshold[0]; a.P.thrB = prm->follow_threshold[1];
     a.P.tir = prm->tir_handling; a.P.key0 = (uint32_t)prm->seed; a.P.key1 = (uint32_t)(prm->seed >> 32);
-    a.table = ctx->d_table; a.n_live = ctx->d_steps; a.n_scat = ctx->d_steps + K;
+    a.table = d_table; a.n_live = d_steps; a.n_scat = d_steps + K;
     a.prof = ctx->d_counters + 8; a.head = ctx->d_counters; a.tail = ctx->d_counters + 1; a.rec_count = ctx->d_counters + 2; a.overflow = (int*)(ctx->d_counters + 3);
     a.rec = (double*)b_rec.p; a.rec_cap = rec_cap; a.rec_step = (int32_t*)b_rstep.p; a.rec_ray = (int64_t*)b_rray.p; a.rec_parent = (int64_t*)b_rpar.p; a.rec_flags = (int32_t*)b_rflag.p;
     a.fin = (double*)b_fin.p; a.rows_lds = rows_lds; a.refill_min = ctx->refill_min;
     if (origin) { a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2]; }
-    a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base;
+    const int64_t stride = prm->ray_id_stride > 0 ? prm->ray_id_stride : 1;
+    a.id_stride = stride;
+    a.cam = ctx->d_cam; a.cam_base = prm->ray_id_base - ctx->cam_first; // mode 3: pixel = ray id - cam_base
     a.hit_l = (double*)b_hl.p; a.hit_so = (int32_t*)b_hso.p;
     // k_level_phys variants: 3 = geometry without UNIFIED surfaces; 1 + 2 = those rays in a launch of their own; 0 = one launch
     const bool nu = !ctx->has_unified;
@@ -1266,8 +1336,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     HitArgs ha; memset(&ha, 0, sizeof ha);
     ha.prog = a.prog; ha.nprog = a.nprog; ha.recs = ctx->d_recs; ha.surf = ctx->d_surf; ha.smeta = ctx->d_smeta; ha.S = S;
     ha.min_travel = a.P.min_travel; ha.base = a.P.base; ha.compat = a.P.compat; ha.hit_l = (double*)b_hl.p; ha.hit_so = (int32_t*)b_hso.p;
-    ha.lean = (single && !out) ? 1 : 0;
-    const size_t lds_hit = (size_t)TQ_DOUBLES * 8, lds_phys = (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 32;
+    ha.lean = a.lean = (single && !out) ? 1 : 0; // one decision for the writers (k_level_init, k_level_phys) and the readers (k_level_hit, k_level_phys, k_level_compact)
+    const size_t lds_hit = (size_t)TQ_DOUBLES * 8, lds_phys = lds_phys_bytes(S);
     if (level) {
         if (lds_phys > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
         CK(hipFuncSetAttribute((const void*)kphys, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_phys));
@@ -1280,7 +1350,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     for (int64_t off = 0; off < n && rc == 0; off += chunk) {
         int64_t m = std::min<int64_t>(chunk, n - off);
         CK(hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
-        a.mode = mode; a.n_in = m; a.ray_id_base = prm->ray_id_base + off; a.slot_base = prm->ray_id_base + off;
+        a.mode = mode; a.n_in = m; a.ray_id_base = prm->ray_id_base + off * stride; a.slot_base = a.ray_id_base;
         if (fin_dev) a.fin = ctx->d_fin_user + (size_t)off * FIN;
         if (mode == 0) {
             if (d_soa) { a.in_d = d_soa + off; a.in_stride = soa_stride > 0 ? soa_stride : n; }
@@ -1378,6 +1448,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 }
                 ctx->n_launches += (defer ? 3 : 2) * nb;
                 int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
+                if (ovf == 3) { ctx->err = "rt_trace: internal error: a ray left a physics step with a direction or polarisation reference that is not a unit vector"; rc = -1; break; }
                 if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace or lower nodice_chunk)" : "rt_trace: ray queue overflow (lower nodice_chunk)"; rc = -3; break; }
                 live = (int64_t)nxt; k0 += nb;
             }
@@ -1407,6 +1478,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             float ms = 0; CK(hipEventElapsedTime(&ms, ev0, ev1)); ctx->kernel_ms += ms; ctx->n_launches++;
             ctx->ms_kind[0] += ms; ctx->n_kind[0]++;
             int ovf = (int)(cnt[3] & 0xFFFFFFFFull);
+            if (ovf == 3) { ctx->err = "rt_trace: internal error: a ray left a physics step with a direction or polarisation reference that is not a unit vector"; rc = -1; break; }
             if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace or lower nodice_chunk)" : "rt_trace: ray queue overflow (lower nodice_chunk)"; rc = -3; break; }
             unsigned long long spawned = cnt[1];
             if (spawned == 0) break;
@@ -1428,7 +1500,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 CK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_ready[s], 0));
                 CK(hipMemcpyAsync(ctx->pin[s], stg[s].dev.p, rec_bytes * (size_t)nrec, hipMemcpyDeviceToHost, ctx->copy_stream));
                 CK(hipEventRecord(ctx->ev_copied[s], ctx->copy_stream));
-                stg[s].nrec = (int64_t)nrec; stg[s].first = prm->ray_id_base + off; stg[s].m = m; stg[s].pending = true;
+                stg[s].nrec = (int64_t)nrec; stg[s].first = prm->ray_id_base + off * stride; stg[s].m = m; stg[s].pending = true;
             }
             rc = drain(s ^ 1); // the previous chunk goes to the sink while this one is copied; the next one is traced under the same copy
             if (rc) break;
@@ -1451,7 +1523,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 for (size_t i = base; i < base + nrec; i++) if (ctx->rec_parent[i] >= 0) ctx->rec_parent[i] += (int64_t)base;
                 if (ctx->sink) { // streaming: this chunk's records (self-contained: parents are chunk-local) go to the caller now
                     int src = ctx->sink(ctx->sink_user, (int64_t)nrec, ctx->rec.data(), ctx->rec_step.data(), ctx->rec_ray.data(), ctx->rec_parent.data(), ctx->rec_flags.data(),
-                                        prm->ray_id_base + off, m);
+                                        prm->ray_id_base + off * stride, m);
                     ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
                     if (src != 0) { ctx->err = "rt_trace: the record sink asked to stop"; rc = -4; break; }
                 }
@@ -1464,18 +1536,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
         hipStreamSynchronize(ctx->copy_stream); // nothing of this call is in flight when its buffers go back to the pool
     }
     if (rc) return rc;
-    // ---- tallies and the reference's step bookkeeping (RayTracer2.py:266-270, 405-407, 542)
-    ctx->table.assign(telems, 0.0); std::vector<unsigned long long> st(2 * (size_t)K);
-    CK(hipMemcpy(ctx->table.data(), ctx->d_table, telems * 8, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(st.data(), ctx->d_steps, sizeof(unsigned long long) * 2 * (size_t)K, hipMemcpyDeviceToHost));
-    ctx->n_live.assign(K, 0); ctx->n_scat.assign(K, 0);
-    int ns = 0;
-    for (int k = 0; k < K; k++) { ctx->n_live[k] = (int64_t)st[k]; ctx->n_scat[k] = (int64_t)st[K + k]; if (st[k] > 0) ns = k + 1; }
-    if (!ctx->raw_tally) // (a lane of run_trace_lanes leaves the rule to the sum of the lanes)
-    for (int k = 0; k < ns; k++)
-        if (ctx->n_scat[k] == 0) std::fill(ctx->table.begin() + (size_t)k * 5 * S * 2, ctx->table.begin() + (size_t)(k + 1) * 5 * S * 2, 0.0); // `continue` before the tallies
-    ctx->num_steps = ns;
-    return 0;
+    if (ctx->raw_tally) { CK(hipStreamSynchronize(ctx->stream)); return 0; } // a lane of run_trace_lanes: the tallies of all lanes are in one table, fetched when all are done
+    return fetch_tallies(ctx, K);
 }
 
 // Lanes.  The nearest-hit launch is bound by vector issue (0.72 of all cycles, no memory traffic to speak of), the physics
@@ -1495,12 +1557,13 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
     if (!eligible) return run_trace(ctx, mode, h_start, h_rays, d_soa, origin, n, prm);
     const int L = std::min(ctx->lanes, 4);
     rt_ctx* lc[4] = { ctx, nullptr, nullptr, nullptr };
+    for (int j = 1; j < L; j++) { // all of them first: a lane is lent the geometry only once nothing below can fail (rt_free frees what a context points at)
+        if (ctx->lane[j - 1]) continue;
+        rt_ctx* l = nullptr;
+        if (rt_init(ctx->device, &l) != 0) { ctx->err = "rt_trace: cannot create another lane: " + g_init_err; return -1; }
+        l->is_lane = true; ctx->lane[j - 1] = l;
+    }
     for (int j = 1; j < L; j++) {
-        if (!ctx->lane[j - 1]) {
-            rt_ctx* l = nullptr;
-            if (rt_init(ctx->device, &l) != 0) { ctx->err = "rt_trace: cannot create another lane: " + g_init_err; return -1; }
-            l->is_lane = true; ctx->lane[j - 1] = l;
-        }
         rt_ctx* l = lc[j] = ctx->lane[j - 1];
         // the lane sees the parent's geometry and options as they are now
         l->d_surf = ctx->d_surf; l->d_recs = ctx->d_recs; l->d_smeta = ctx->d_smeta; l->d_prog = ctx->d_prog; l->d_lut = ctx->d_lut; l->d_cam = ctx->d_cam;
@@ -1517,7 +1580,7 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
     rt_params pl[4]; int64_t first[4], cnt[4]; int rcs[4] = { 0, 0, 0, 0 };
     for (int j = 0; j < L; j++) {
         first[j] = per * j; cnt[j] = std::max<int64_t>(0, std::min<int64_t>(per, n - first[j]));
-        pl[j] = *prm; pl[j].ray_id_base += first[j];
+        pl[j] = *prm; pl[j].ray_id_base += first[j] * (prm->ray_id_stride > 0 ? prm->ray_id_stride : 1);
         lc[j]->workspace_bytes = W / L; lc[j]->raw_tally = true;
         if (j > 0) { if (fin_user) { lc[j]->d_fin_user = fin_user + (size_t)first[j] * FIN; lc[j]->fin_user_rows = fin_rows - first[j]; } else { lc[j]->d_fin_user = nullptr; lc[j]->fin_user_rows = 0; } }
     }
@@ -1535,6 +1598,13 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
         }
     }
     if (paired) for (int j = 0; j < L; j++) { lc[j]->pair = &pair; lc[j]->pair_id = j; lc[j]->pair_seq = 0; }
+    // one table and one set of step counters for all lanes (the kernels add with atomics anyway): the tallies of the run are
+    // in this context's device table when the lanes are done, as after a run on one lane (rt_result_table_device)
+    const int K = prm->max_scatters, S = ctx->S; const size_t row = (size_t)5 * S * 2;
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "rt_trace: hipSetDevice failed"; return -1; }
+    if (prepare_tallies(ctx, K)) return -1;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "rt_trace: clearing the tallies failed"; return -1; }
+    for (int j = 0; j < L; j++) { lc[j]->d_table_ext = ctx->d_table; lc[j]->d_steps_ext = ctx->d_steps; }
     auto run_lane = [&](int j) {
         if (cnt[j] > 0) rcs[j] = run_trace(lc[j], mode, h_start ? h_start + 3 * first[j] : nullptr, h_rays ? h_rays + 10 * first[j] : nullptr, d_soa ? d_soa + first[j] : nullptr, origin, cnt[j], &pl[j], d_soa ? n : 0);
         pair.done[j].store(1, std::memory_order_release);
@@ -1544,23 +1614,18 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
     run_lane(0);
     for (auto& t : th) t.join();
     ctx->workspace_bytes = W;
-    for (int j = 0; j < L; j++) { lc[j]->pair = nullptr; lc[j]->raw_tally = false; }
+    for (int j = 0; j < L; j++) { lc[j]->pair = nullptr; lc[j]->raw_tally = false; lc[j]->d_table_ext = nullptr; lc[j]->d_steps_ext = nullptr; }
     for (int j = 1; j < L; j++) { rt_ctx* l = lc[j]; l->d_surf = l->d_recs = l->d_prog = l->d_lut = l->d_cam = nullptr; l->d_smeta = nullptr; l->d_fin_user = nullptr; } // not the lanes' to free
     if (rcs[0]) return rcs[0];
     for (int j = 1; j < L; j++) if (rcs[j]) { ctx->err = lc[j]->err; return rcs[j]; }
-    const int K = prm->max_scatters, S = ctx->S; const size_t row = (size_t)5 * S * 2;
+    (void)row;
     for (int j = 1; j < L; j++) {
         rt_ctx* l = lc[j]; if (cnt[j] <= 0) continue;
-        for (size_t i = 0; i < ctx->table.size() && i < l->table.size(); i++) ctx->table[i] += l->table[i];
-        for (int k = 0; k < K; k++) { ctx->n_live[k] += l->n_live[k]; ctx->n_scat[k] += l->n_scat[k]; }
         ctx->kernel_ms += l->kernel_ms; ctx->n_launches += l->n_launches; // sums over the lanes: they overlap in time
         for (int i = 0; i < 3; i++) { ctx->ms_kind[i] += l->ms_kind[i]; ctx->n_kind[i] += l->n_kind[i]; }
     }
-    int ns = 0;
-    for (int k = 0; k < K; k++) if (ctx->n_live[k] > 0) ns = k + 1;
-    for (int k = 0; k < ns; k++) if (ctx->n_scat[k] == 0) std::fill(ctx->table.begin() + (size_t)k * row, ctx->table.begin() + (size_t)(k + 1) * row, 0.0); // RayTracer2.py:405-407 on the whole
-    ctx->num_steps = ns; ctx->n_rays = n;
-    return 0;
+    ctx->K = K; ctx->n_rays = n;
+    return fetch_tallies(ctx, K); // RayTracer2.py:405-407 on the whole
 }
 
 } // namespace
@@ -1599,7 +1664,7 @@ extern "C" int rt_trace_device_noalloc(rt_ctx* ctx, const double* d_soa, int64_t
     if (ctx->has_rayleigh && !ctx->d_lut) { ctx->err = "rt_trace: geometry has finite Rayleigh lengths but no azimuth table was set (rt_set_rayleigh_lut)"; return -1; }
     if (ctx->device >= MAX_DEVICES || !g_scratch_ptr[ctx->device]) { ctx->err = "rt_trace_device_noalloc: no scratch buffer on this device"; return -1; }
     CK(hipSetDevice(ctx->device));
-    const size_t lds_phys = (size_t)S * ROW * 8 + (size_t)5 * S * 2 * 8 + 32;
+    const size_t lds_phys = lds_phys_bytes(S);
     if (lds_phys > 160 * 1024) { ctx->err = "rt_trace: geometry does not fit LDS"; return -1; }
 
     // ---- segments as in run_trace(): nseg blocks, block b owns queue slots [b * seg_cap, (b + 1) * seg_cap) through all steps
@@ -1629,7 +1694,7 @@ extern "C" int rt_trace_device_noalloc(rt_ctx* ctx, const double* d_soa, int64_t
     a.P.tir = prm->tir_handling; a.P.key0 = (uint32_t)prm->seed; a.P.key1 = (uint32_t)(prm->seed >> 32);
     a.table = d_table; a.n_live = (unsigned long long*)d_step_counts; a.n_scat = (unsigned long long*)d_step_counts + K;
     a.head = counters; a.tail = counters + 1; a.rec_count = counters + 2; a.overflow = (int*)(counters + 3); a.prof = counters + 8;
-    a.hit_l = hit_l; a.hit_so = hit_so; a.rows_lds = 1; a.refill_min = ctx->refill_min;
+    a.hit_l = hit_l; a.hit_so = hit_so; a.rows_lds = 1; a.refill_min = ctx->refill_min; a.lean = 1;
     const bool defer = ctx->has_unified && ctx->defer_unified;
     void (*kphys)(const KArgs) = defer ? k_level_phys<FLAG_SINGLE, 1> : (ctx->has_unified ? k_level_phys<FLAG_SINGLE, 0> : k_level_phys<FLAG_SINGLE, 3>);
     void (*kphys2)(const KArgs) = k_level_phys<FLAG_SINGLE, 2>;
@@ -1645,7 +1710,7 @@ extern "C" int rt_trace_device_noalloc(rt_ctx* ctx, const double* d_soa, int64_t
     uint32_t* sg[2] = { seg, seg + nseg };
 
     // initial rays -> queue 1 (step 0 writes queue 0)
-    a.mode = 0; a.in_d = d_soa; a.in_stride = n; a.n_in = n; a.ray_id_base = prm->ray_id_base; a.slot_base = prm->ray_id_base;
+    a.mode = 0; a.in_d = d_soa; a.in_stride = n; a.n_in = n; a.ray_id_base = prm->ray_id_base; a.slot_base = prm->ray_id_base; a.id_stride = prm->ray_id_stride > 0 ? prm->ray_id_stride : 1;
     a.out = q[1]; a.seg_out = sg[1];
     hipLaunchKernelGGL(k_level_init<0>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, a);
     a.mode = 1; a.in_d = q[1].d; a.in_i = q[1].i; a.in_m = q[1].m; a.in_stride = q_cap;
@@ -1691,7 +1756,19 @@ int upload_camera(rt_ctx* ctx, const rt_camera* cam, int64_t* n_pix) {
 extern "C" int rt_trace_camera(rt_ctx* ctx, const rt_camera* cam, const rt_params* prm) {
     int64_t n = 0;
     if (upload_camera(ctx, cam, &n)) return -1;
+    if (prm->ray_id_stride > 1) { ctx->err = "rt_trace_camera: a stride needs a pixel range (rt_trace_camera_range)"; return -1; }
+    ctx->cam_first = 0;
     return run_trace(ctx, 3, nullptr, nullptr, nullptr, nullptr, n, prm);
+}
+extern "C" int rt_trace_camera_range(rt_ctx* ctx, const rt_camera* cam, int64_t first, int64_t n, const rt_params* prm) {
+    int64_t npix = 0;
+    if (upload_camera(ctx, cam, &npix)) return -1;
+    const int64_t stride = prm->ray_id_stride > 0 ? prm->ray_id_stride : 1;
+    if (first < 0 || n < 1 || first + (n - 1) * stride >= npix) { ctx->err = "rt_trace_camera_range: pixel range outside the sensor"; return -1; }
+    ctx->cam_first = first;
+    const int rc = run_trace(ctx, 3, nullptr, nullptr, nullptr, nullptr, n, prm);
+    ctx->cam_first = 0;
+    return rc;
 }
 extern "C" int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, int64_t n, double* start, double* rays, int32_t* pixels) {
     int64_t npix = 0;
@@ -1710,7 +1787,7 @@ extern "C" int rt_generate_point_source(rt_ctx* ctx, const double origin[3], int
     CK(hipSetDevice(ctx->device));
     DevBuf s, r; CK(dev_alloc(ctx, s, 24 * (size_t)n)); CK(dev_alloc(ctx, r, 80 * (size_t)n));
     KArgs a; memset(&a, 0, sizeof a);
-    a.P.key0 = (uint32_t)seed; a.P.key1 = (uint32_t)(seed >> 32); a.ray_id_base = ray_id_base; a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
+    a.P.key0 = (uint32_t)seed; a.P.key1 = (uint32_t)(seed >> 32); a.ray_id_base = ray_id_base; a.id_stride = 1; a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
     hipLaunchKernelGGL(k_gen_point, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, n, (double*)s.p, (double*)r.p);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(start, s.p, 24 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1729,6 +1806,17 @@ extern "C" int rt_debug_profile(rt_ctx* ctx, unsigned long long* out8, int reset
 }
 extern "C" int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps) { *num_steps = ctx->num_steps; return 0; }
 extern "C" int rt_result_table(rt_ctx* ctx, double* table) { memcpy(table, ctx->table.data(), sizeof(double) * (size_t)ctx->num_steps * 5 * ctx->S * 2); return 0; }
+extern "C" int rt_result_table_device(rt_ctx* ctx, double* d_table, uint64_t* d_step_counts) {
+    if (!d_table || ctx->K < 1 || !ctx->d_table) { ctx->err = "rt_result_table_device: no trace to report, or no destination"; return -1; }
+    const int K = ctx->K; const size_t telems = (size_t)K * 5 * ctx->S * 2;
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpyAsync(d_table, ctx->d_table, telems * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_level_finish, dim3((unsigned)K), dim3(BLOCK), 0, ctx->stream, d_table, (const unsigned long long*)ctx->d_steps + K, 5 * ctx->S * 2); // RayTracer2.py:405-407
+    CK(hipGetLastError());
+    if (d_step_counts) CK(hipMemcpyAsync(d_step_counts, ctx->d_steps, sizeof(uint64_t) * 2 * (size_t)K, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 extern "C" int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live, int64_t* n_scat) {
     memcpy(n_live, ctx->n_live.data(), 8 * (size_t)ctx->K); memcpy(n_scat, ctx->n_scat.data(), 8 * (size_t)ctx->K); return 0;
 }
@@ -1755,6 +1843,104 @@ extern "C" int rt_split_record_fields(const double* rows, int64_t n_rows, const 
         for (auto& t : th) t.join();
     }
     return bad ? -2 : 0;
+}
+// ---- host work of the drop-in call, off the interpreter (python/RayTracer2.py:221-222 and :531-540 for 10^7 rows)
+namespace {
+template <class F> void parallel_ranges(int64_t n, int64_t grain, F f) { // f(thread, first, last) over [0, n) on up to 16 host threads
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(grain, 1)));
+    if (nt <= 1) { f(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th; const int64_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) th.emplace_back(f, t, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+    for (auto& t : th) t.join();
+}
+int parallel_threads(int64_t n, int64_t grain) { return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(grain, 1))); }
+// entries >= 0 of tab[0..m) in index order appended to out; returns how many.  (two passes: counts per thread, then the copy)
+int64_t compact_table(const int64_t* tab, int64_t m, int64_t* out) {
+    const int nt = parallel_threads(m, 1 << 16);
+    std::vector<int64_t> cnt((size_t)nt + 1, 0);
+    parallel_ranges(m, 1 << 16, [&](int t, int64_t a, int64_t b) { int64_t c = 0; for (int64_t i = a; i < b; i++) c += tab[i] >= 0; cnt[(size_t)t + 1] = c; });
+    for (int t = 0; t < nt; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
+    parallel_ranges(m, 1 << 16, [&](int t, int64_t a, int64_t b) { int64_t o = cnt[(size_t)t]; for (int64_t i = a; i < b; i++) if (tab[i] >= 0) out[o++] = tab[i]; });
+    return cnt[(size_t)nt];
+}
+} // namespace
+// The caller's rays normalised in place as the reference does it to the caller's array (python/RayTracer2.py:221-222:
+// columns 0-2 and 3-5 divided by |sqrt(sum of squares)|, the same operations in the same order as the numpy expression,
+// so the same bits), on several host threads.
+extern "C" int rt_normalize_rays(double* rays, int64_t n) {
+    if (!rays || n < 0) return -1;
+    parallel_ranges(n, 1 << 15, [&](int, int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; i++) {
+            double* r = rays + 10 * i;
+            for (int c = 0; c < 6; c += 3) {
+#pragma clang fp contract(off)
+                const double s = fabs(sqrt((r[c] * r[c] + r[c + 1] * r[c + 1]) + r[c + 2] * r[c + 2]));
+                r[c] = r[c] / s; r[c + 1] = r[c + 1] / s; r[c + 2] = r[c + 2] / s;
+            }
+        }
+    });
+    return 0;
+}
+// Row order of the reference for the records of a trace (python/RayTracer2.py:531-540: step 0 in input order; step k + 1 =
+// [refracted children in the order of their parents ; reflected children in the order of their parents]) from the ordering
+// metadata of rt_result_records.  order[0..n): record indices, step after step; counts[k]: records of step k.  Tables
+// instead of sorts: a record of step k + 1 is the only child of its kind of its parent, so its place follows from the
+// parent's place by one scatter and one compaction - O(n) on several threads where numpy's lexsort per step took longer than
+// the trace.  Returns 0, or -2 if the metadata is not of that form (the caller then sorts: RayTracer2.order_records).
+extern "C" int rt_order_records(const int32_t* step, const int64_t* ray_id, const int64_t* parent, const int32_t* flags, int64_t n, int32_t num_steps,
+                                int64_t* order, int64_t* counts) {
+    if (n < 0 || num_steps < 0 || (n > 0 && (!step || !ray_id || !parent || !flags || !order)) || (num_steps > 0 && !counts)) return -1;
+    for (int k = 0; k < num_steps; k++) counts[k] = 0;
+    if (n == 0 || num_steps == 0) return 0;
+    // records of every step, in record order
+    std::vector<int64_t> start((size_t)num_steps + 1, 0);
+    for (int64_t r = 0; r < n; r++) { if (step[r] < 0) return -2; if (step[r] < num_steps) start[(size_t)step[r] + 1]++; }
+    for (int k = 0; k < num_steps; k++) start[(size_t)k + 1] += start[(size_t)k];
+    std::vector<int64_t> by_step((size_t)start[(size_t)num_steps]), fill(start.begin(), start.end() - 1);
+    for (int64_t r = 0; r < n; r++) if (step[r] < num_steps) by_step[(size_t)fill[(size_t)step[r]]++] = r;
+    std::vector<int64_t> pos((size_t)n, -1); // place of a record within its step
+    std::atomic<int> bad{ 0 };
+    int64_t at = 0;
+    // step 0: by ray id (one record per ray): a table over the id range
+    {
+        const int64_t m = start[1];
+        if (m > 0) {
+            int64_t lo = ray_id[by_step[0]], hi = lo;
+            for (int64_t j = 0; j < m; j++) { const int64_t v = ray_id[by_step[(size_t)j]]; lo = std::min(lo, v); hi = std::max(hi, v); }
+            const int64_t span = hi - lo + 1;
+            if (span > 64 * m + (1 << 20)) return -2; // ids too sparse for a table
+            std::vector<int64_t> tab((size_t)span, -1);
+            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) { const int64_t r = by_step[(size_t)j]; int64_t& e = tab[(size_t)(ray_id[r] - lo)]; if (e >= 0) bad = 1; e = r; } });
+            if (bad) return -2; // two records of one ray in step 0
+            const int64_t got = compact_table(tab.data(), span, order);
+            if (got != m) return -2;
+            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) pos[(size_t)order[j]] = j; });
+        }
+        counts[0] = m; at = m;
+    }
+    for (int k = 1; k < num_steps; k++) {
+        const int64_t m = start[(size_t)k + 1] - start[(size_t)k], mp = counts[k - 1];
+        const int64_t* rec = by_step.data() + start[(size_t)k];
+        if (m > 0) {
+            if (mp <= 0) return -2;
+            std::vector<int64_t> tab((size_t)(2 * mp), -1); // [born refracted: by the parent's place | born reflected: by the parent's place]
+            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) {
+                for (int64_t j = a; j < b; j++) {
+                    const int64_t r = rec[j], p = parent[r];
+                    if (p < 0 || p >= n || step[p] != k - 1 || pos[(size_t)p] < 0) { bad = 1; continue; }
+                    int64_t& e = tab[(size_t)(((flags[r] & 4) ? mp : 0) + pos[(size_t)p])];
+                    if (e >= 0) bad = 1; // a second child of the same kind: not the reference's tree
+                    e = r;
+                }
+            });
+            if (bad) return -2;
+            if (compact_table(tab.data(), 2 * mp, order + at) != m) return -2;
+            int64_t* o = order + at;
+            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) pos[(size_t)o[j]] = j; });
+        }
+        counts[k] = m; at += m;
+    }
+    return 0;
 }
 extern "C" int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_t n, int32_t nfields, const int32_t* col0, const int32_t* ncols, double* const* outs) {
     const int rc = rt_split_record_fields(ctx->rec.data(), (int64_t)ctx->rec_step.size(), order, n, nfields, col0, ncols, outs);

@@ -408,9 +408,85 @@ def check_unified_facet_law(trace, n=200000):
     return out
 
 
+def check_unified_dielectric_reemission(trace, n=120000):
+    """UNIFIED sigma_alpha > 0 on a dielectric-dielectric panel (UnifiedReflectorModel.m:196-203, 257-266): light that a
+    facet transmits is inside the surface material, comes back as Lambertian re-emission about the mechanical normal -
+    unpolarised, times P_diffuse-reemit - and has to cross the rough boundary again on its way out.
+    (i) Index-matched panel (n 1.33 | 1.33): no facet reflects and none bends, so EVERY ray is re-emitted once and leaves
+    as it was re-emitted: Lambert's law about the panel normal (<cos> = 2/3, cos^2 and azimuth uniform), unpolarised, with
+    exactly P_reemit of its intensity; the rest is the surface's absorption (tally 0).  Steep and 60 degree incidence.
+    (ii) Vacuum | glass with P_reemit = 1, lobe only: whatever happens in between - reflection off the first facet,
+    re-emission, total reflection back into the material and another re-emission - every ray comes back out with all of
+    its intensity (reflected + absorbed = 1 per ray, absorbed = 0), upwards, a unit vector with a unit reference normal to it."""
+    out = {}
+    for theta, pre in ((0.2, 0.8), (np.pi / 3, 0.55)):
+        panel = mk('matched panel', 'plane', [np.array([0, 0, 0.]), np.array([0, 0, 1.])], everywhere_plane, 1.33, 1.33, 'unified', 0.0,
+                   unifiedparams=[0.15, pre, 0.3, 0.3, 0.2])
+        d = np.tile([np.sin(theta), 0, -np.cos(theta)], (n, 1)); sp = np.tile([0.0, 0, 4.0], (n, 1))
+        res = trace(sp, rays_from(d, polref=[0, 1.0, 0], stokes=(1, 0.6, -0.3, 0.2)), [absorbing_sphere(30.0, n_in=1.33), panel], 1, 1e-9, 0.0, -1.0, True, False, False,
+                    seed=123, **MATLAB)
+        ri = res.ray_interfaces[0]
+        assert ri.ray_index.size == n and np.all(np.abs(ri.surface_index) == 2)
+        o = ri.reflected_ray
+        assert np.abs(o[:, 6] - pre).max() < 1e-12 and np.abs(o[:, 7:10]).max() == 0.0            # P_reemit of the ray, unpolarised
+        assert np.abs(ri.refracted_ray[:, 6]).max() == 0.0                                          # nothing is transmitted through a UNIFIED surface (RayTracer2.py:444)
+        c = o[:, 2]; phi = np.arctan2(o[:, 1], o[:, 0])
+        assert c.min() > 0 and np.abs(np.linalg.norm(o[:, 0:3], axis=1) - 1).max() < 1e-12
+        assert np.abs(np.sum(o[:, 0:3] * o[:, 3:6], axis=1)).max() < 1e-12 and np.abs(np.linalg.norm(o[:, 3:6], axis=1) - 1).max() < 1e-12
+        assert abs(c.mean() - 2.0 / 3.0) < 3 * np.sqrt(1.0 / 18.0 / n), c.mean()                   # Lambert: p(c) = 2c, var = 1/18
+        chi2, dof = chi2_ok(np.histogram(c * c, bins=20, range=(0, 1))[0], np.full(20, n / 20.0), "re-emission cos^2, incidence %.2f" % theta)
+        chi2_ok(np.histogram(phi, bins=16, range=(-np.pi, np.pi))[0], np.full(16, n / 16.0), "re-emission azimuth, incidence %.2f" % theta)
+        tab = res.absorption_table
+        assert abs(tab[0, 0, 1, :].sum() - (1 - pre) * n) < 1e-9 * n                                # absorbed in the panel: the rest of every ray
+        out[round(theta, 2)] = (round(chi2, 1), dof)
+    glass = mk('glass panel', 'plane', [np.array([0, 0, 0.]), np.array([0, 0, 1.])], everywhere_plane, 1.0, 1.5, 'unified', 0.0,
+               unifiedparams=[0.1, 1.0, 1.0, 0.0, 0.0])
+    m = n // 4
+    d = np.tile([np.sin(0.5), 0, -np.cos(0.5)], (m, 1)); sp = np.tile([0.0, 0, 4.0], (m, 1))
+    res = trace(sp, rays_from(d, polref=[0, 1.0, 0], stokes=(1, 0.5, 0.5, 0)), [absorbing_sphere(30.0), glass], 1, 1e-9, 0.0, -1.0, True, False, False, seed=321, **MATLAB)
+    o = res.ray_interfaces[0].reflected_ray
+    assert o.shape[0] == m and np.abs(o[:, 6] - 1).max() < 1e-12 and o[:, 2].min() > 0
+    assert np.abs(np.linalg.norm(o[:, 0:3], axis=1) - 1).max() < 1e-12 and np.abs(np.linalg.norm(o[:, 3:6], axis=1) - 1).max() < 1e-9
+    assert np.abs(np.sum(o[:, 0:3] * o[:, 3:6], axis=1)).max() < 1e-9
+    assert np.all(np.hypot(np.hypot(o[:, 7], o[:, 8]), o[:, 9]) <= o[:, 6] * (1 + 1e-12))           # physical Stokes vectors
+    assert abs(res.absorption_table[0, 0, 1, :].sum()) < 1e-9 * m                                  # nothing absorbed: reflected + absorbed = 1 per ray
+    mostly_reemitted = np.mean(np.abs(o[:, 7]) < 0.45)                                              # a first-facet reflection keeps |s1| ~ 0.5, re-emitted light is polarised by its exit alone
+    assert 0.85 < mostly_reemitted < 0.99, mostly_reemitted                                          # ~ 1 - R(0.5 rad) of a 1 -> 1.5 interface
+    out["glass"] = round(float(mostly_reemitted), 3)
+    return out
+
+
+def check_raytable_rule(trace, n=400):
+    """output_raytable (MATLAB/RayTracer2.m:249-253, 543-548; the numpy port's is broken) on SURVEY config 1 in
+    ray-splitting mode: layer 1 holds the starting points and the normalised rays; layer k + 1 holds, for every ray whose
+    lineage has never been reflected (ray_index > 0) and that scattered in step k, the point of that scatter and its
+    refracted child; everything else stays zero.  The expected table is built here from the records of the same call
+    (pinned by the reference's fixtures) - by the rule as the MATLAB lines state it, not by the wrapper's code."""
+    sp, rays = cases.isotropic_rays(n, 4, origin=(3, 0, 0))
+    rays[:, 0:3] *= 2.5                                                                              # not normalised on purpose (:244-245)
+    K = 7
+    res = trace(sp, rays.copy(), cases.sphere_plane(), K, 1e-9, 1e-6, -1.0, True, False, True, **MATLAB)
+    rt = np.asarray(res.raytable)
+    assert rt.shape == (K + 1, n, 13)
+    want = np.zeros_like(rt)
+    want[0, :, 0:3] = sp; want[0, :, 3:13] = rays
+    want[0, :, 3:6] /= np.linalg.norm(want[0, :, 3:6], axis=1, keepdims=True); want[0, :, 6:9] /= np.linalg.norm(want[0, :, 6:9], axis=1, keepdims=True)
+    rows = 0
+    for k, ri in enumerate(res.ray_interfaces):
+        cut = ri.ray_index > 0
+        ix = np.round(ri.ray_index[cut]).astype(np.int64) - 1                                       # 1-based MATLAB indices
+        assert np.unique(ix).size == ix.size                                                        # a never-reflected lineage is one ray per step
+        want[k + 1, ix, 0:3] = ri.intersection_point[cut]; want[k + 1, ix, 3:13] = ri.refracted_ray[cut]
+        rows += ix.size
+    assert rows > 1.1 * n and len(res.ray_interfaces) >= 4 and np.any(want[2])                      # (step 0: every ray; step 1: the rays that leave the sphere towards the plane)
+    assert np.array_equal(rt[0], want[0]) or np.abs(rt[0] - want[0]).max() < 1e-15
+    assert np.array_equal(rt[1:], want[1:])
+    return {"rows": rows, "steps": len(res.ray_interfaces)}
+
+
 def check_torus_first_hit_in_frame(trace):
     return check_torus_first_hit(trace, seed=8, coaxial=True)
 
 
 ALL_CHECKS = (check_torus_first_hit, check_torus_first_hit_in_frame, check_quadric_closed_forms, check_beer_lambert, check_diffuse_lambert, check_retro, check_rayleigh_law,
-              check_fresnel_known_answers, check_unified_facet_law)
+              check_fresnel_known_answers, check_unified_facet_law, check_unified_dielectric_reemission)

@@ -108,6 +108,7 @@ def test_config5_full_mc_one_batch():
             prm = c.params(kw["K"], _lib.FLAG_SINGLECHILD, 0, kw["min_travel"], kw["thr"], kw["tir"], 2024, base)
             c._check(c.L.rt_trace_point_source(c.h, org, m, C.byref(prm)))
             return c.results(False, False, m)["table"], c.step_counts(kw["K"])
+        c.set_option("lanes", 1)                                  # one lane first (the library's default is two for a run of this size)
         t, (live, scat) = run(n, 0)
         assert abs(_total(t) - n) < 1e-9 * n
         assert live[0] == n and np.all(np.diff(live) <= 0) and scat.sum() > 3 * n

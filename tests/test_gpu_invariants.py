@@ -23,7 +23,7 @@ def gpu_tracer(options):
             out = RayTracer2(sp, rays.copy(), sl, *args, ctx=c, **kw)
         finally:
             c.close()
-        return types.SimpleNamespace(ray_interfaces=list(out[0]), absorption_table=out[1])
+        return types.SimpleNamespace(ray_interfaces=list(out[0]), absorption_table=out[1], raytable=out[2])
     return trace
 
 
@@ -31,3 +31,8 @@ def gpu_tracer(options):
 @pytest.mark.parametrize("check", inv.ALL_CHECKS, ids=lambda f: f.__name__)
 def test_gpu_known_answers(check, path):
     print(check.__name__, path, check(gpu_tracer(PATHS[path])))
+
+
+@pytest.mark.parametrize("path", ["default", "persistent"])
+def test_gpu_raytable_rule(path):
+    print(inv.check_raytable_rule(gpu_tracer(PATHS[path])))

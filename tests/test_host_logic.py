@@ -115,7 +115,6 @@ def test_product_never_imports_oracle():
     for dp, _, files in os.walk(os.path.join(ROOT, "raytracer_amd")):
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h")):
-                assert "oracle" not in open(os.path.join(dp, f)).read().replace("the oracle", "").replace("The oracle", "").replace("oracle/", "").replace("the CPU oracle", "") or True
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M) and "librt_oracle" not in src and "rt_oracle.c\"" not in src, f
 
@@ -176,3 +175,55 @@ def test_geometry_key_sees_a_changed_closure_and_a_changed_global():
     s.inbounds_function = lambda p: np.reshape(p[:, 2, :] < bound[0], (p.shape[0], -1))
     k3 = R._surface_fingerprint(s); bound[0] = 6.0
     assert R._surface_fingerprint(s) != k3
+
+
+def _random_record_tree(rng, n_rays, K, split):
+    """ordering metadata of a trace as the device leaves it: records of a random tree (dice mode: one child per record;
+    ray splitting: up to one refracted and one reflected child), shuffled"""
+    step, ray, parent, flags = [], [], [], []
+    cur = []                                     # (record index, ray) of the previous step
+    for r in rng.permutation(n_rays)[: max(1, int(0.9 * n_rays))]:
+        step.append(0); ray.append(int(r) + 1000); parent.append(-1); flags.append(2); cur.append(len(step) - 1)
+    for k in range(1, K):
+        nxt = []
+        for p in cur:
+            kids = [b for b in (0, 1) if rng.random() < (0.45 if split else 0.0)] if split else ([int(rng.random() < 0.3)] if rng.random() < 0.8 else [])
+            for born in kids:
+                step.append(k); ray.append(ray[p]); parent.append(p); flags.append((4 if born else 0) | (1 if (born or flags[p] & 1) else 0)); nxt.append(len(step) - 1)
+        cur = nxt
+    n = len(step); perm = rng.permutation(n); inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    step = np.array(step, np.int32)[perm]; ray = np.array(ray, np.int64)[perm]; flags = np.array(flags, np.int32)[perm]
+    parent = np.array(parent, np.int64)[perm]; parent = np.where(parent >= 0, inv[np.maximum(parent, 0)], -1)
+    return step, ray, parent, flags
+
+
+def test_library_orders_records_like_the_numpy_rule_and_normalises_like_numpy():
+    """rt_order_records / rt_normalize_rays (plain host code of the library: no GPU needed) against the numpy statements of
+    python/RayTracer2.py:531-540 and :221-222 they replace in the drop-in call"""
+    import ctypes as C
+    from raytracer_amd import _lib
+    from raytracer_amd.RayTracer2 import order_records, order_groups
+    rng = np.random.default_rng(5)
+    for split, n_rays, K in ((False, 3000, 7), (True, 400, 9), (False, 1, 3), (True, 70000, 4)):
+        step, ray, parent, flags = _random_record_tree(rng, n_rays, K, split)
+        want = order_records(step, ray, parent, flags, K)
+        got = order_groups(step, ray, parent, flags, K)
+        assert len(got) == len(want) == K
+        for a_, b_ in zip(got, want):
+            assert np.array_equal(a_, b_)
+    # metadata that is not such a tree: the library declines (-2) and order_groups falls back to the sort
+    L = _lib.load()
+    step = np.array([0, 0], np.int32); ray = np.array([5, 5], np.int64); parent = np.array([-1, -1], np.int64); flags = np.zeros(2, np.int32)
+    order = np.zeros(2, np.int64); counts = np.zeros(1, np.int64)
+    I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    assert L.rt_order_records(step.ctypes.data_as(I32), ray.ctypes.data_as(I64), parent.ctypes.data_as(I64), flags.ctypes.data_as(I32), 2, 1, order.ctypes.data_as(I64), counts.ctypes.data_as(I64)) == -2
+    assert [list(g) for g in order_groups(step, ray, parent, flags, 1)] == [list(g) for g in order_records(step, ray, parent, flags, 1)]
+    # normalisation: the same bits as the numpy expression, zero and non-finite rows included
+    rays = rng.normal(size=(200001, 10)) * 10.0 ** rng.integers(-150, 150, size=(200001, 1))
+    rays[7, 0:3] = 0; rays[9, 3:6] = np.inf; rays[11, 1] = np.nan
+    want = rays.copy()
+    with np.errstate(all="ignore"):
+        want[:, 0:3] = want[:, 0:3] / np.abs(np.sqrt(np.sum(want[:, 0:3] ** 2, axis=1, keepdims=True)))
+        want[:, 3:6] = want[:, 3:6] / np.abs(np.sqrt(np.sum(want[:, 3:6] ** 2, axis=1, keepdims=True)))
+    assert L.rt_normalize_rays(rays.ctypes.data_as(C.POINTER(C.c_double)), rays.shape[0]) == 0
+    assert np.array_equal(rays, want, equal_nan=True)

@@ -18,6 +18,10 @@ def test_oracle_known_answers(check):
     print(check.__name__, check(oracle_trace))
 
 
+def test_oracle_raytable_rule():
+    print(inv.check_raytable_rule(oracle_trace))
+
+
 def test_torus_all_roots_and_classification_vs_numpy_roots():
     """unit level (ora_ray_to_shape): all four roots of 10 200 rays, real/complex classification included, against
     numpy.roots of the coefficients of RayToTorus.m:97-103; near-tangent rays (two roots within 1e-6) excluded, counted"""

@@ -33,6 +33,13 @@ def _both(c, sp, rays, K, thr, seed):
     cnt = torch.full((2, K), 9, dtype=torch.int64, device="cuda:0")
     torch.cuda.synchronize()
     c._check(c.L.rt_trace_device_noalloc(c.h, C.c_void_p(d.data_ptr()), n, C.byref(prm), C.c_void_p(tab.data_ptr()), C.c_void_p(cnt.data_ptr())))
+    # what the entry point is for: the call (kernel code loaded by the one above) leaves the device's free memory where it was
+    tab2 = torch.full((K, 5, S, 2), 7.0, dtype=torch.float64, device="cuda:0"); cnt2 = torch.full((2, K), 9, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    c._check(c.L.rt_trace_device_noalloc(c.h, C.c_void_p(d.data_ptr()), n, C.byref(prm), C.c_void_p(tab2.data_ptr()), C.c_void_p(cnt2.data_ptr())))
+    assert torch.cuda.mem_get_info(0)[0] == free0, "rt_trace_device_noalloc changed the free device memory"
+    assert torch.equal(cnt2, cnt) and np.allclose(tab2.cpu().numpy(), tab.cpu().numpy(), rtol=1e-10, atol=1e-10 * n)
     tab = tab.cpu().numpy(); cnt = cnt.cpu().numpy()
     assert np.array_equal(cnt[0], live) and np.array_equal(cnt[1], scat)
     ns = ref["num_steps"]
@@ -61,6 +68,13 @@ def test_noalloc_entry_point_equals_rt_trace_device(scene):
         ns1 = _both(c, sp, rays, K, 1e-4, 17)
         ns2 = _both(c, sp[:7003], rays[:7003], K, 1e-4, 18)                    # smaller input into the same scratch array
         assert ns1 >= 3 and ns2 >= 3
+        c2 = Context(0)                                                        # a second context on the same GPU shares the scratch array: calls one after the other
+        try:
+            c2.set_surfaces(sl); c2.set_option("level_min_rays", 0)
+            assert _both(c2, sp[:20011], rays[:20011], K, 1e-4, 19) >= 3
+            assert _both(c, sp[:5001], rays[:5001], K, 1e-4, 20) >= 3          # and the first one again behind it
+        finally:
+            c2.close()
         # limits: refused with a clear error, nothing run
         prm = c.params(K, _lib.FLAG_SINGLECHILD, 0, 1e-7, (1e-4, 1e-4), 0.5, 1, 0)
         assert c.L.rt_trace_device_noalloc(c.h, C.c_void_p(8), _lib.NOALLOC_MAX_RAYS + 1, C.byref(prm), C.c_void_p(8), C.c_void_p(8)) != 0

@@ -4,7 +4,7 @@
 # Usage: tools/profile_counters.sh TAG [bench args]   ->  gpurun_out/counters_TAG.json (copy to profiles/counters.json)
 TAG=$1; shift
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --lanes 1 --no-one-lane --rays 4194304 $@"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --lanes 1 --no-one-lane $@"   # the bench's own batch (33.5 M rays per step), one lane: every launch alone on the GPU
 run() { name=$1; shift; timeout -s KILL 150 rocprofv3 --pmc "$@" -d gpurun_out/pmc_${TAG}_$name -o pmc --output-format csv -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/pmc_${TAG}_$name.log; exit 1; }; }
 run f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE
 run rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU

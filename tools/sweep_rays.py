@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--lo", type=int, default=15); ap.add_argument("--hi", type=int, default=26)
     ap.add_argument("--opt", default="", help="name=v1,v2,...: repeat the largest size for every value of this context option")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--set", default="", help="name=value[,name=value...]: context options for the whole sweep")
     a = ap.parse_args()
     import torch  # noqa: F401  (one HIP runtime per process: see raytracer_amd/_lib.py)
     import bench
@@ -27,6 +28,8 @@ def main():
     from raytracer_amd.RayTracer2 import Context
     sl, prog, origin, kw = bench.build_workload(a.workload)
     ctx = Context(0); ctx.set_program(*prog)
+    for kv in filter(None, a.set.split(",")):
+        ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     org = (C.c_double * 3)(*origin)
     flags = kw.get("flags", _lib.FLAG_SINGLECHILD)
 
