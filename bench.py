@@ -183,7 +183,10 @@ def main():
             if backend != "nccl":
                 tt = tt.cpu()
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            table_sum[0] = float(tt.sum())
+            # conservation on the all-reduced table (RunSBCGeometry.m:87-92): absorbed + escaped + dropped over all steps, plus
+            # what is still followed after the last one = the rays of all ranks
+            rows = tt.reshape(tt.shape[0], 5, -1).sum(-1).cpu().numpy(); nz = np.nonzero(rows.any(axis=1))[0]
+            table_sum[0] = float(rows[:, 0:4].sum() + (rows[nz[-1], 4] if nz.size else 0.0))
         ms = C.c_double(); nl = C.c_int32(); ctx.L.rt_result_timing(ctx.h, C.byref(ms), C.byref(nl))
         bk = (C.c_double * 3)(); bn = (C.c_int32 * 3)(); ctx.L.rt_result_timing_by_kernel(ctx.h, bk, bn)
         for j in range(3):
@@ -274,7 +277,7 @@ def main():
                                             for j, n in enumerate(names)}},
         }
         if table_sum[0] is not None:
-            out["config"]["allreduced_table_sum_last_step"] = table_sum[0]
+            out["config"]["allreduced_table_rays_accounted_last_step"] = table_sum[0]
         if world == 1 and lanes != 1 and not a.no_one_lane and cam is None and h_sp is None:
             # Not the headline value: the same K steps again with one lane, every launch alone on the GPU - the per-kernel times
             # and the roofline of the dominant kernel without the other lane's launches beside it.

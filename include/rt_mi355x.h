@@ -284,7 +284,7 @@ int rt_split_record_fields(const double* rows /*[n_rows][RT_REC_COLS]*/, int64_t
  * [refracted children in the order of their parents ; reflected children in the order of their parents]) from the ordering
  * metadata of rt_result_records: order[0..n) = record indices, step after step; counts[k] = records of step k.  Returns 0,
  * -1 (bad arguments) or -2 (metadata that is not a tree of that form, e.g. ray ids too sparse for a table: sort instead). */
-int rt_normalize_rays(double* rays /*[n][10]*/, int64_t n);
+int rt_normalize_rays(double* rays /*[n][10]*/, int64_t n, double* max_s0 /* NULL, or: the largest rays[:,6] (NaN if any is), RayTracer2.py:252 */);
 int rt_order_records(const int32_t* step, const int64_t* ray_id, const int64_t* parent, const int32_t* flags, int64_t n, int32_t num_steps,
                      int64_t* order /*[n]*/, int64_t* counts /*[num_steps]*/);
 int rt_result_final(rt_ctx* ctx, double* rows /*[n_rays][RT_FINAL_COLS]*/);

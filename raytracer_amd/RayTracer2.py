@@ -111,8 +111,8 @@ class Context(object):
         if want_records:
             n = C.c_int64(); self._check(self.L.rt_result_num_records(self.h, C.byref(n))); n = n.value
             meta_only = isinstance(want_records, str) and want_records == "meta"  # the rows stay in the library: interfaces() splits them into fields
-            rec = None if meta_only else np.zeros((n, _lib.REC_COLS))
-            step = np.zeros(n, np.int32); ray = np.zeros(n, np.int64); par = np.zeros(n, np.int64); fl = np.zeros(n, np.int32)
+            rec = None if meta_only else np.empty((n, _lib.REC_COLS))
+            step = np.empty(n, np.int32); ray = np.empty(n, np.int64); par = np.empty(n, np.int64); fl = np.empty(n, np.int32)
             if n:
                 self._check(self.L.rt_result_records(self.h, None if meta_only else _dp(rec), step.ctypes.data_as(C.POINTER(C.c_int32)), ray.ctypes.data_as(C.POINTER(C.c_int64)),
                                                      par.ctypes.data_as(C.POINTER(C.c_int64)), fl.ctypes.data_as(C.POINTER(C.c_int32))))
@@ -386,15 +386,15 @@ _FIELDS = (("incoming_ray", 0, 10), ("refracted_ray", 10, 10), ("reflected_ray",
            ("orientation", 45, 1), ("surface_number", 46, 1), ("is_rayleigh", 47, 1))
 
 
-def parse_args(rays, max_scat, min_travel_len, follow_thresh, tir_handling, compat):
-    """argument handling of python/RayTracer2.py:193-212, 250-255 (scalars accepted everywhere)"""
+def parse_args(rays, max_scat, min_travel_len, follow_thresh, tir_handling, compat, max_s0=None):
+    """argument handling of python/RayTracer2.py:193-212, 250-255 (scalars accepted everywhere); max_s0: max(rays[:, 6]) if the caller has it"""
     ft = np.atleast_1d(np.asarray(follow_thresh, dtype=np.float64)).ravel()
     thr = (float(ft[0]), float(ft[0])) if ft.size == 1 else (float(ft[0]), float(ft[1]))
     K = int(np.atleast_1d(max_scat).ravel()[0])
     mtl = float(np.atleast_1d(min_travel_len).ravel()[0])
     if tir_handling is None or np.size(tir_handling) == 0:
         ref = thr[0] if (COMPAT[compat] & _lib.COMPAT_PY_INDEX) else thr[1]  # RayTracer2.py:252 vs RayTracer2.m:279
-        tir = 1.0 if ref > np.max(rays[:, 6]) else -1.0
+        tir = 1.0 if ref > (np.max(rays[:, 6]) if max_s0 is None else max_s0) else -1.0
     else:
         tir = float(np.atleast_1d(tir_handling).ravel()[0])
     return K, mtl, thr, tir
@@ -405,8 +405,8 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
                output_raytable=False, *, compat="python", seed=None, device=0, return_final=False, ray_id_base=0, ctx=None,
                unified_maxiter=0, record_sink=None, ray_id_stride=1, device_table=False):
     # error check inputs (python/RayTracer2.py:216-217), before any device work
-    if np.size(surfacelist) == 0 or np.array(ray_startingpoints).ndim != 2 or np.array(rays).ndim != 2 or \
-            np.size(ray_startingpoints, 1) != 3 or np.size(rays, 1) != 10 or np.size(ray_startingpoints, 0) != np.size(rays, 0):
+    if np.size(surfacelist) == 0 or np.ndim(ray_startingpoints) != 2 or np.ndim(rays) != 2 or \
+            np.shape(ray_startingpoints)[1] != 3 or np.shape(rays)[1] != 10 or np.shape(ray_startingpoints)[0] != np.shape(rays)[0]:
         raise Exception('Improper input to RayTracer2')
     if compat not in COMPAT:
         raise ValueError("compat must be one of %r" % (sorted(COMPAT),))
@@ -415,16 +415,19 @@ def RayTracer2(ray_startingpoints, rays, surfacelist=[], max_scat=10, min_travel
     n = ry.shape[0]
     if n == 0:
         raise Exception('Improper input to RayTracer2')
-    K, mtl, thr, tir = parse_args(ry, max_scat, min_travel_len, follow_thresh, tir_handling, compat)
     # the reference normalises the caller's array in place (python/RayTracer2.py:221-222); keep that visible effect
+    max_s0 = None
     if isinstance(rays, np.ndarray) and rays.dtype == np.float64:
         L_ = _lib.load()
         if rays.flags.c_contiguous and rays.flags.writeable and hasattr(L_, "rt_normalize_rays") and not NUMPY_NORMALISE:
-            L_.rt_normalize_rays(_dp(rays), n)   # the same operations on several host threads (the numpy expression takes longer than the trace)
+            m_ = C.c_double()   # the same operations on several host threads (the numpy expression takes longer than the trace), and max(rays[:, 6]) on the way
+            if L_.rt_normalize_rays(_dp(rays), n, C.byref(m_)) == 0:
+                max_s0 = m_.value
         else:
             with np.errstate(all="ignore"):
                 rays[:, 0:3] = rays[:, 0:3] / np.abs(np.sqrt(np.sum(rays[:, 0:3] ** 2, axis=1, keepdims=True)))
                 rays[:, 3:6] = rays[:, 3:6] / np.abs(np.sqrt(np.sum(rays[:, 3:6] ** 2, axis=1, keepdims=True)))
+    K, mtl, thr, tir = parse_args(ry, max_scat, min_travel_len, follow_thresh, tir_handling, compat, max_s0)
     # missing optional attributes get the reference's defaults on the caller's objects (RayTracer2.py:234-248)
     for s in surfacelist:
         if not hasattr(s, "unifiedparams") or np.size(s.unifiedparams) == 0:

@@ -92,7 +92,7 @@ def load():
     L.rt_result_record_fields.argtypes = [C.c_void_p, P(C.c_int64), C.c_int64, C.c_int32, P(C.c_int32), P(C.c_int32), P(P(C.c_double))]
     L.rt_split_record_fields.argtypes = [P(C.c_double), C.c_int64, P(C.c_int64), C.c_int64, C.c_int32, P(C.c_int32), P(C.c_int32), P(P(C.c_double))]
     try:
-        L.rt_normalize_rays.argtypes = [P(C.c_double), C.c_int64]
+        L.rt_normalize_rays.argtypes = [P(C.c_double), C.c_int64, P(C.c_double)]
         L.rt_order_records.argtypes = [P(C.c_int32), P(C.c_int64), P(C.c_int64), P(C.c_int32), C.c_int64, C.c_int32, P(C.c_int64), P(C.c_int64)]
     except AttributeError:
         if "RT_LIB" not in os.environ:

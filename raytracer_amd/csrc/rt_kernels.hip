@@ -24,6 +24,8 @@
 #include <atomic>
 #include <thread>
 #include <mutex>
+#include <memory>
+#include <algorithm>
 
 #define RT_HD __host__ __device__ __forceinline__
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1867,11 +1869,14 @@ int64_t compact_table(const int64_t* tab, int64_t m, int64_t* out) {
 // The caller's rays normalised in place as the reference does it to the caller's array (python/RayTracer2.py:221-222:
 // columns 0-2 and 3-5 divided by |sqrt(sum of squares)|, the same operations in the same order as the numpy expression,
 // so the same bits), on several host threads.
-extern "C" int rt_normalize_rays(double* rays, int64_t n) {
+extern "C" int rt_normalize_rays(double* rays, int64_t n, double* max_s0) {
     if (!rays || n < 0) return -1;
-    parallel_ranges(n, 1 << 15, [&](int, int64_t a, int64_t b) {
+    const int nt = parallel_threads(n, 1 << 15);
+    std::vector<double> mx((size_t)nt, -INFINITY); std::vector<char> nan((size_t)nt, 0);
+    parallel_ranges(n, 1 << 15, [&](int t, int64_t a, int64_t b) {
         for (int64_t i = a; i < b; i++) {
             double* r = rays + 10 * i;
+            if (r[6] != r[6]) nan[(size_t)t] = 1; else if (r[6] > mx[(size_t)t]) mx[(size_t)t] = r[6];
             for (int c = 0; c < 6; c += 3) {
 #pragma clang fp contract(off)
                 const double s = fabs(sqrt((r[c] * r[c] + r[c + 1] * r[c + 1]) + r[c + 2] * r[c + 2]));
@@ -1879,6 +1884,7 @@ extern "C" int rt_normalize_rays(double* rays, int64_t n) {
             }
         }
     });
+    if (max_s0) { double m = -INFINITY; bool any_nan = false; for (int t = 0; t < nt; t++) { m = std::max(m, mx[(size_t)t]); any_nan |= nan[(size_t)t] != 0; } *max_s0 = any_nan ? NAN : m; } // numpy.max: NaN if any
     return 0;
 }
 // Row order of the reference for the records of a trace (python/RayTracer2.py:531-540: step 0 in input order; step k + 1 =
@@ -1893,42 +1899,58 @@ extern "C" int rt_order_records(const int32_t* step, const int64_t* ray_id, cons
     for (int k = 0; k < num_steps; k++) counts[k] = 0;
     if (n == 0 || num_steps == 0) return 0;
     // records of every step, in record order
-    std::vector<int64_t> start((size_t)num_steps + 1, 0);
-    for (int64_t r = 0; r < n; r++) { if (step[r] < 0) return -2; if (step[r] < num_steps) start[(size_t)step[r] + 1]++; }
-    for (int k = 0; k < num_steps; k++) start[(size_t)k + 1] += start[(size_t)k];
-    std::vector<int64_t> by_step((size_t)start[(size_t)num_steps]), fill(start.begin(), start.end() - 1);
-    for (int64_t r = 0; r < n; r++) if (step[r] < num_steps) by_step[(size_t)fill[(size_t)step[r]]++] = r;
-    std::vector<int64_t> pos((size_t)n, -1); // place of a record within its step
     std::atomic<int> bad{ 0 };
+    const int nt = parallel_threads(n, 1 << 16);
+    std::vector<int64_t> cnt((size_t)nt * num_steps, 0); // per thread and step
+    parallel_ranges(n, 1 << 16, [&](int t, int64_t a, int64_t b) {
+        int64_t* c = cnt.data() + (size_t)t * num_steps;
+        for (int64_t r = a; r < b; r++) { if (step[r] < 0) { bad = 1; continue; } if (step[r] < num_steps) c[step[r]]++; }
+    });
+    if (bad) return -2;
+    std::vector<int64_t> start((size_t)num_steps + 1, 0);
+    { int64_t at_ = 0; for (int k = 0; k < num_steps; k++) { start[(size_t)k] = at_; for (int t = 0; t < nt; t++) { const int64_t c = cnt[(size_t)t * num_steps + k]; cnt[(size_t)t * num_steps + k] = at_; at_ += c; } } start[(size_t)num_steps] = at_; }
+    std::unique_ptr<int64_t[]> by_step_buf(new int64_t[(size_t)start[(size_t)num_steps] + 1]); int64_t* by_step = by_step_buf.get();
+    parallel_ranges(n, 1 << 16, [&](int t, int64_t a, int64_t b) {
+        int64_t* c = cnt.data() + (size_t)t * num_steps;
+        for (int64_t r = a; r < b; r++) if (step[r] < num_steps) by_step[c[step[r]]++] = r;
+    });
+    std::unique_ptr<int64_t[]> pos_buf(new int64_t[(size_t)n]); int64_t* pos = pos_buf.get(); // place of a record within its step (written before it is read: every parent is placed a step earlier)
+    parallel_ranges(n, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t r = a; r < b; r++) pos[r] = -1; });
     int64_t at = 0;
     // step 0: by ray id (one record per ray): a table over the id range
     {
         const int64_t m = start[1];
         if (m > 0) {
             int64_t lo = ray_id[by_step[0]], hi = lo;
-            for (int64_t j = 0; j < m; j++) { const int64_t v = ray_id[by_step[(size_t)j]]; lo = std::min(lo, v); hi = std::max(hi, v); }
+            { const int nt0 = parallel_threads(m, 1 << 16); std::vector<int64_t> los((size_t)nt0, lo), his((size_t)nt0, hi);
+              parallel_ranges(m, 1 << 16, [&](int t, int64_t a, int64_t b) { int64_t l_ = lo, h_ = hi; for (int64_t j = a; j < b; j++) { const int64_t v = ray_id[by_step[j]]; l_ = std::min(l_, v); h_ = std::max(h_, v); } los[(size_t)t] = l_; his[(size_t)t] = h_; });
+              for (int t = 0; t < nt0; t++) { lo = std::min(lo, los[(size_t)t]); hi = std::max(hi, his[(size_t)t]); } }
             const int64_t span = hi - lo + 1;
             if (span > 64 * m + (1 << 20)) return -2; // ids too sparse for a table
-            std::vector<int64_t> tab((size_t)span, -1);
-            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) { const int64_t r = by_step[(size_t)j]; int64_t& e = tab[(size_t)(ray_id[r] - lo)]; if (e >= 0) bad = 1; e = r; } });
+            std::unique_ptr<int64_t[]> tab_buf(new int64_t[(size_t)span]); int64_t* tab_ = tab_buf.get();
+            parallel_ranges(span, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) tab_[i] = -1; });
+            struct { int64_t* p; int64_t& operator[](size_t i) { return p[i]; } int64_t* data() { return p; } } tab{ tab_ };
+            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) { const int64_t r = by_step[j]; int64_t& e = tab[(size_t)(ray_id[r] - lo)]; if (e >= 0) bad = 1; e = r; } });
             if (bad) return -2; // two records of one ray in step 0
             const int64_t got = compact_table(tab.data(), span, order);
             if (got != m) return -2;
-            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) pos[(size_t)order[j]] = j; });
+            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) pos[order[j]] = j; });
         }
         counts[0] = m; at = m;
     }
     for (int k = 1; k < num_steps; k++) {
         const int64_t m = start[(size_t)k + 1] - start[(size_t)k], mp = counts[k - 1];
-        const int64_t* rec = by_step.data() + start[(size_t)k];
+        const int64_t* rec = by_step + start[(size_t)k];
         if (m > 0) {
             if (mp <= 0) return -2;
-            std::vector<int64_t> tab((size_t)(2 * mp), -1); // [born refracted: by the parent's place | born reflected: by the parent's place]
+            std::unique_ptr<int64_t[]> tab_buf(new int64_t[(size_t)(2 * mp)]); int64_t* tab_ = tab_buf.get(); // [born refracted: by the parent's place | born reflected: by the parent's place]
+            parallel_ranges(2 * mp, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) tab_[i] = -1; });
+            struct { int64_t* p; int64_t& operator[](size_t i) { return p[i]; } int64_t* data() { return p; } } tab{ tab_ };
             parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) {
                 for (int64_t j = a; j < b; j++) {
                     const int64_t r = rec[j], p = parent[r];
-                    if (p < 0 || p >= n || step[p] != k - 1 || pos[(size_t)p] < 0) { bad = 1; continue; }
-                    int64_t& e = tab[(size_t)(((flags[r] & 4) ? mp : 0) + pos[(size_t)p])];
+                    if (p < 0 || p >= n || step[p] != k - 1 || pos[p] < 0) { bad = 1; continue; }
+                    int64_t& e = tab[(size_t)(((flags[r] & 4) ? mp : 0) + pos[p])];
                     if (e >= 0) bad = 1; // a second child of the same kind: not the reference's tree
                     e = r;
                 }
@@ -1936,7 +1958,7 @@ extern "C" int rt_order_records(const int32_t* step, const int64_t* ray_id, cons
             if (bad) return -2;
             if (compact_table(tab.data(), 2 * mp, order + at) != m) return -2;
             int64_t* o = order + at;
-            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) pos[(size_t)o[j]] = j; });
+            parallel_ranges(m, 1 << 16, [&](int, int64_t a, int64_t b) { for (int64_t j = a; j < b; j++) pos[o[j]] = j; });
         }
         counts[k] = m; at += m;
     }

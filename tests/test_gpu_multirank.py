@@ -69,7 +69,7 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["unit"] == "interactions/s" and two["steps"] == 2
     n = 1 << 20
     # every ray ends in exactly one of the tallies (RunSBCGeometry.m:87-92): the all-reduced table of the last step sums to both ranks' rays
-    assert abs(two["config"]["allreduced_table_sum_last_step"] - 2 * n) < 1e-6 * 2 * n
+    assert abs(two["config"]["allreduced_table_rays_accounted_last_step"] - 2 * n) < 1e-6 * 2 * n
     # weak scaling on a shared GPU: both ranks' interactions are counted (twice the rays, the same interactions per ray) ...
     assert abs(two["config"]["interactions_per_ray"] - one["config"]["interactions_per_ray"]) < 0.01 * one["config"]["interactions_per_ray"]
     # ... and the rate is that of one GPU doing both shares, not a per-rank figure: between half and twice the one-rank rate

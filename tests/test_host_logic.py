@@ -225,5 +225,8 @@ def test_library_orders_records_like_the_numpy_rule_and_normalises_like_numpy():
     with np.errstate(all="ignore"):
         want[:, 0:3] = want[:, 0:3] / np.abs(np.sqrt(np.sum(want[:, 0:3] ** 2, axis=1, keepdims=True)))
         want[:, 3:6] = want[:, 3:6] / np.abs(np.sqrt(np.sum(want[:, 3:6] ** 2, axis=1, keepdims=True)))
-    assert L.rt_normalize_rays(rays.ctypes.data_as(C.POINTER(C.c_double)), rays.shape[0]) == 0
-    assert np.array_equal(rays, want, equal_nan=True)
+    mx = C.c_double(0.0)
+    assert L.rt_normalize_rays(rays.ctypes.data_as(C.POINTER(C.c_double)), rays.shape[0], C.byref(mx)) == 0
+    assert np.array_equal(rays, want, equal_nan=True) and mx.value == np.max(want[:, 6])
+    rays[5, 6] = np.nan
+    assert L.rt_normalize_rays(rays.ctypes.data_as(C.POINTER(C.c_double)), rays.shape[0], C.byref(mx)) == 0 and np.isnan(mx.value)   # numpy.max: NaN if any
