@@ -687,6 +687,7 @@ template <bool TWO> RT_HD void frame_candidates(const Geom& G, const Prm& P, con
     const double lmin = (six_last == n + P.base) ? P.min_travel : 0.0; // RayTracer2.py:316
     const bool first = n < h.surf;
     bool c0_ = act & ok0 & wins_nb(l0, lmin, h.l, first), c1_ = TWO ? (act & ok1 & wins_nb(l1, lmin, h.l, first)) : false;
+    if (!RT_ANY(c0_ | c1_)) return; // no ray of the wave has a root here in front of its best hit (nearest hit: -1.8 %)
     const uint32_t na = (mlo >> 16) & 3u;
     if (na > 0) { const uint32_t ck = (mlo >> 20) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, prec_w(R, 9), l0), prec_w(R, 7), prec_w(R, 8)); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, prec_w(R, 9), l1), prec_w(R, 7), prec_w(R, 8)); }
     if (na > 1) { const uint32_t ck = (mlo >> 24) & 3u; c0_ = c0_ & in_range(frame_coord(F, ck, prec_w(R, 12), l0), prec_w(R, 10), prec_w(R, 11)); if (TWO) c1_ = c1_ & in_range(frame_coord(F, ck, prec_w(R, 12), l1), prec_w(R, 10), prec_w(R, 11)); }

@@ -413,6 +413,7 @@ template <int CF, bool LEAN = false, bool GEN = true, int UNI = 0> __global__ vo
         PROF_ADD(1)
         if constexpr (LEAN) {
             LeanBounce b; bounce_phys_single<UNI>(G, P, q, h, b, alive); // every lane (UNI = 1: the wave works through the rough-surface loop together)
+            PROF_ADD(2)
             if (alive) {
                 const int k = q.k;
                 atomicAdd(&s_live[k], 1u);
@@ -426,6 +427,7 @@ template <int CF, bool LEAN = false, bool GEN = true, int UNI = 0> __global__ vo
                     else q = lean_child(q, b);
                 }
             }
+            PROF_ADD(3)
             continue;
         }
         Bounce b; b.scat = 0;
