@@ -261,7 +261,7 @@ def main():
                        "ray_surface_tests_per_s": inter_all * S / dt},
             "roofline": dict({"bound": "fp64_valu", "achieved": counter_tflops if counter_tflops is not None else ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": (counter_tflops if counter_tflops is not None else ach) / FP64_VALU_PEAK_TFLOPS,
-                              "basis": "executed" if counter_tflops is not None else "algorithmic (profiles/counters.json is not from these kernel sources: no executed-flop figure)",
+                              "basis": "executed" if counter_tflops is not None else "algorithmic (profiles/counters.json is not from these kernel sources or not of this workload: no executed-flop figure)",
                               "algorithmic_achieved": ach, "algorithmic_frac": ach / FP64_VALU_PEAK_TFLOPS,
                               "traffic": traffic, "counter_tflops": counter_tflops, "valu_issue_frac": valu_issue_frac,
                               "note": "achieved/frac = FP64 flops the kernel EXECUTED per second (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2, per unit "
