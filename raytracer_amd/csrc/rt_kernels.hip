@@ -1579,6 +1579,15 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
         l->upload_chunk = ctx->upload_chunk; l->stream_overlap = ctx->stream_overlap;
     }
     const size_t W = ctx->workspace_bytes;
+    // whatever way this function is left, the lanes give back what they were lent (rt_free frees what a context points at)
+    struct Unlend {
+        rt_ctx* c; rt_ctx** lc; int L; size_t W;
+        ~Unlend() {
+            c->workspace_bytes = W;
+            for (int j = 0; j < L; j++) { if (!lc[j]) continue; lc[j]->pair = nullptr; lc[j]->raw_tally = false; lc[j]->d_table_ext = nullptr; lc[j]->d_steps_ext = nullptr; }
+            for (int j = 1; j < L; j++) { rt_ctx* l = lc[j]; if (!l) continue; l->d_surf = l->d_recs = l->d_prog = l->d_lut = l->d_cam = nullptr; l->d_smeta = nullptr; l->d_fin_user = nullptr; }
+        }
+    } unlend{ ctx, lc, L, W };
     const int64_t per = ((n + L - 1) / L + 255) & ~(int64_t)255; // rays of a lane (the last one takes what is left: n >= lanes_min_rays, so it is not empty)
     double* fin_user = ctx->d_fin_user; const int64_t fin_rows = ctx->fin_user_rows;
     rt_params pl[4]; int64_t first[4], cnt[4]; int rcs[4] = { 0, 0, 0, 0 };
@@ -1617,9 +1626,8 @@ static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const d
     for (int j = 1; j < L; j++) th.emplace_back(run_lane, j);
     run_lane(0);
     for (auto& t : th) t.join();
-    ctx->workspace_bytes = W;
+    ctx->workspace_bytes = W; // (fetch_tallies below is this context's own work again; the rest is given back by `unlend`)
     for (int j = 0; j < L; j++) { lc[j]->pair = nullptr; lc[j]->raw_tally = false; lc[j]->d_table_ext = nullptr; lc[j]->d_steps_ext = nullptr; }
-    for (int j = 1; j < L; j++) { rt_ctx* l = lc[j]; l->d_surf = l->d_recs = l->d_prog = l->d_lut = l->d_cam = nullptr; l->d_smeta = nullptr; l->d_fin_user = nullptr; } // not the lanes' to free
     if (rcs[0]) return rcs[0];
     for (int j = 1; j < L; j++) if (rcs[j]) { ctx->err = lc[j]->err; return rcs[j]; }
     (void)row;
