@@ -866,8 +866,12 @@ struct RawBuf {
 static void parallel_copy(void* dst, const void* src, size_t bytes) {
     const int nt = (int)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), bytes >> 24);
     if (nt <= 1) { memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> th; const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
-    for (int t = 0; t < nt; t++) { const size_t o = std::min(bytes, (size_t)t * per), e = std::min(bytes, o + per); if (e > o) th.emplace_back([=] { memcpy((char*)dst + o, (const char*)src + o, e - o); }); }
+    std::vector<std::thread> th; th.reserve((size_t)nt); const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+    auto piece = [=](int t) { const size_t o = std::min(bytes, (size_t)t * per), e = std::min(bytes, o + per); if (e > o) memcpy((char*)dst + o, (const char*)src + o, e - o); };
+    int started = 0;
+    for (int t = 1; t < nt; t++) { try { th.emplace_back(piece, t); started = t; } catch (...) { break; } } // (a thread that cannot be started: its piece is copied here)
+    piece(0);
+    for (int t = started + 1; t < nt; t++) piece(t);
     for (auto& t : th) t.join();
 }
 
@@ -1832,6 +1836,30 @@ extern "C" int rt_result_table_device(rt_ctx* ctx, double* d_table, uint64_t* d_
 extern "C" int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live, int64_t* n_scat) {
     memcpy(n_live, ctx->n_live.data(), 8 * (size_t)ctx->K); memcpy(n_scat, ctx->n_scat.data(), 8 * (size_t)ctx->K); return 0;
 }
+// ---- host work of the drop-in call, off the interpreter (python/RayTracer2.py:221-222 and :531-540 for 10^7 rows)
+namespace {
+template <class F> void parallel_ranges(int64_t n, int64_t grain, F f) { // f(thread, first, last) over [0, n) on up to 16 host threads
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(grain, 1)));
+    if (nt <= 1) { f(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th; th.reserve((size_t)nt); const int64_t per = (n + nt - 1) / nt;
+    auto lo = [&](int t) { return std::min<int64_t>(n, t * per); };
+    int started = 0;
+    for (int t = 1; t < nt; t++) { try { th.emplace_back(f, t, lo(t), lo(t + 1)); started = t; } catch (...) { break; } } // (a thread that cannot be started: its range is done here)
+    f(0, lo(0), lo(1));
+    for (int t = started + 1; t < nt; t++) f(t, lo(t), lo(t + 1));
+    for (auto& t : th) t.join();
+}
+int parallel_threads(int64_t n, int64_t grain) { return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(grain, 1))); }
+// entries >= 0 of tab[0..m) in index order appended to out; returns how many.  (two passes: counts per thread, then the copy)
+int64_t compact_table(const int64_t* tab, int64_t m, int64_t* out) {
+    const int nt = parallel_threads(m, 1 << 16);
+    std::vector<int64_t> cnt((size_t)nt + 1, 0);
+    parallel_ranges(m, 1 << 16, [&](int t, int64_t a, int64_t b) { int64_t c = 0; for (int64_t i = a; i < b; i++) c += tab[i] >= 0; cnt[(size_t)t + 1] = c; });
+    for (int t = 0; t < nt; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
+    parallel_ranges(m, 1 << 16, [&](int t, int64_t a, int64_t b) { int64_t o = cnt[(size_t)t]; for (int64_t i = a; i < b; i++) if (tab[i] >= 0) out[o++] = tab[i]; });
+    return cnt[(size_t)nt];
+}
+} // namespace
 // Records order[0..n) of a row table split into fields: field f = columns [col0[f], col0[f] + ncols[f]) as a dense
 // [n][ncols[f]] array at outs[f].  One pass over the rows, on several host threads for large n.  Returns 0, -1 (bad
 // column range) or -2 (record index out of range).
@@ -1847,39 +1875,13 @@ extern "C" int rt_split_record_fields(const double* rows, int64_t n_rows, const 
             for (int f = 0; f < nfields; f++) { double* o = outs[f] + (size_t)j * ncols[f]; const double* r = row + col0[f]; for (int c = 0; c < ncols[f]; c++) o[c] = r[c]; }
         }
     };
-    int nt = (int)std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / 65536);
-    if (nt <= 1) work(0, n);
-    else {
-        std::vector<std::thread> th; const int64_t per = (n + nt - 1) / nt;
-        for (int t = 0; t < nt; t++) th.emplace_back(work, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
-        for (auto& t : th) t.join();
-    }
+    parallel_ranges(n, 65536, [&](int, int64_t a, int64_t b) { work(a, b); });
     return bad ? -2 : 0;
 }
-// ---- host work of the drop-in call, off the interpreter (python/RayTracer2.py:221-222 and :531-540 for 10^7 rows)
-namespace {
-template <class F> void parallel_ranges(int64_t n, int64_t grain, F f) { // f(thread, first, last) over [0, n) on up to 16 host threads
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(grain, 1)));
-    if (nt <= 1) { f(0, (int64_t)0, n); return; }
-    std::vector<std::thread> th; const int64_t per = (n + nt - 1) / nt;
-    for (int t = 0; t < nt; t++) th.emplace_back(f, t, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
-    for (auto& t : th) t.join();
-}
-int parallel_threads(int64_t n, int64_t grain) { return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(grain, 1))); }
-// entries >= 0 of tab[0..m) in index order appended to out; returns how many.  (two passes: counts per thread, then the copy)
-int64_t compact_table(const int64_t* tab, int64_t m, int64_t* out) {
-    const int nt = parallel_threads(m, 1 << 16);
-    std::vector<int64_t> cnt((size_t)nt + 1, 0);
-    parallel_ranges(m, 1 << 16, [&](int t, int64_t a, int64_t b) { int64_t c = 0; for (int64_t i = a; i < b; i++) c += tab[i] >= 0; cnt[(size_t)t + 1] = c; });
-    for (int t = 0; t < nt; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
-    parallel_ranges(m, 1 << 16, [&](int t, int64_t a, int64_t b) { int64_t o = cnt[(size_t)t]; for (int64_t i = a; i < b; i++) if (tab[i] >= 0) out[o++] = tab[i]; });
-    return cnt[(size_t)nt];
-}
-} // namespace
 // The caller's rays normalised in place as the reference does it to the caller's array (python/RayTracer2.py:221-222:
 // columns 0-2 and 3-5 divided by |sqrt(sum of squares)|, the same operations in the same order as the numpy expression,
 // so the same bits), on several host threads.
-extern "C" int rt_normalize_rays(double* rays, int64_t n, double* max_s0) {
+extern "C" int rt_normalize_rays(double* rays, int64_t n, double* max_s0) try {
     if (!rays || n < 0) return -1;
     const int nt = parallel_threads(n, 1 << 15);
     std::vector<double> mx((size_t)nt, -INFINITY); std::vector<char> nan((size_t)nt, 0);
@@ -1896,7 +1898,7 @@ extern "C" int rt_normalize_rays(double* rays, int64_t n, double* max_s0) {
     });
     if (max_s0) { double m = -INFINITY; bool any_nan = false; for (int t = 0; t < nt; t++) { m = std::max(m, mx[(size_t)t]); any_nan |= nan[(size_t)t] != 0; } *max_s0 = any_nan ? NAN : m; } // numpy.max: NaN if any
     return 0;
-}
+} catch (...) { return -1; } // (only the two small vectors above can throw, before anything is written; the caller then normalises with numpy)
 // Row order of the reference for the records of a trace (python/RayTracer2.py:531-540: step 0 in input order; step k + 1 =
 // [refracted children in the order of their parents ; reflected children in the order of their parents]) from the ordering
 // metadata of rt_result_records.  order[0..n): record indices, step after step; counts[k]: records of step k.  Tables
@@ -1904,7 +1906,7 @@ extern "C" int rt_normalize_rays(double* rays, int64_t n, double* max_s0) {
 // parent's place by one scatter and one compaction - O(n) on several threads where numpy's lexsort per step took longer than
 // the trace.  Returns 0, or -2 if the metadata is not of that form (the caller then sorts: RayTracer2.order_records).
 extern "C" int rt_order_records(const int32_t* step, const int64_t* ray_id, const int64_t* parent, const int32_t* flags, int64_t n, int32_t num_steps,
-                                int64_t* order, int64_t* counts) {
+                                int64_t* order, int64_t* counts) try {
     if (n < 0 || num_steps < 0 || (n > 0 && (!step || !ray_id || !parent || !flags || !order)) || (num_steps > 0 && !counts)) return -1;
     for (int k = 0; k < num_steps; k++) counts[k] = 0;
     if (n == 0 || num_steps == 0) return 0;
@@ -1973,7 +1975,7 @@ extern "C" int rt_order_records(const int32_t* step, const int64_t* ray_id, cons
         counts[k] = m; at += m;
     }
     return 0;
-}
+} catch (...) { return -1; } // (no memory for the tables, no thread: the caller sorts instead)
 extern "C" int rt_result_record_fields(rt_ctx* ctx, const int64_t* order, int64_t n, int32_t nfields, const int32_t* col0, const int32_t* ncols, double* const* outs) {
     const int rc = rt_split_record_fields(ctx->rec.data(), (int64_t)ctx->rec_step.size(), order, n, nfields, col0, ncols, outs);
     if (rc == -1) ctx->err = "rt_result_record_fields: bad column range";
