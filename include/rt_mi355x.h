@@ -256,6 +256,13 @@ int rt_match_endpoints(rt_ctx* ctx, const double* cam_rows /*[n_cam][RT_FINAL_CO
 
 /* Results of the last trace. */
 int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps);           /* rows of absorption_table (RayTracer2.py:542) */
+/* Ray-splitting runs (no RT_FLAG_SINGLECHILD) are traced in passes of `nodice_chunk` rays, and a pass cannot know in
+ * advance how many rays and records it will hold at once (the reference grows its arrays as it goes,
+ * python/RayTracer2.py:531-540).  A pass whose queue or record buffer overflows is traced again from its first ray in
+ * passes a quarter the size - its tallies went into a table of its own, which is dropped - and the call goes on; only when
+ * that has failed eight times (or the pass is down to 256 rays) does rt_trace return -3 (the caller then lowers
+ * nodice_chunk and starts over).  *n: how many passes of the last trace were repeated that way (diagnostic). */
+int rt_result_pass_retries(rt_ctx* ctx, int32_t* n);
 int rt_result_table(rt_ctx* ctx, double* table /* [num_steps][5][n_surf][2] */);
 int rt_result_step_counts(rt_ctx* ctx, int64_t* n_live /*[K]*/, int64_t* n_scat /*[K]*/);
 /* The table of the last trace without the trip through host memory: all max_scatters rows [K][5][n_surf][2] (rows of steps

@@ -13,7 +13,7 @@ COMPAT_PY_INDEX, COMPAT_PY_ROOT2 = 1, 2
 NOALLOC_MAX_RAYS, NOALLOC_MAX_SCATTERS = 262144, 4094
 
 EXPORTS = ("rt_init", "rt_free", "rt_last_error", "rt_set_surfaces", "rt_set_rayleigh_lut", "rt_trace", "rt_trace_device", "rt_trace_device_noalloc",
-           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_trace_camera_range", "rt_generate_camera_rays", "rt_result_table_device", "rt_set_record_sink", "rt_set_final_rows_device", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_table",
+           "rt_trace_point_source", "rt_generate_point_source", "rt_trace_camera", "rt_trace_camera_range", "rt_generate_camera_rays", "rt_result_table_device", "rt_set_record_sink", "rt_set_final_rows_device", "rt_match_endpoints", "rt_set_option", "rt_result_num_steps", "rt_result_pass_retries", "rt_result_table",
            "rt_result_step_counts", "rt_result_num_records", "rt_result_records", "rt_result_record_fields", "rt_split_record_fields", "rt_normalize_rays", "rt_order_records", "rt_result_final", "rt_result_timing",
            "rt_result_timing_by_kernel", "rt_device_info")
 
@@ -85,6 +85,11 @@ def load():
     L.rt_set_final_rows_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.rt_result_num_steps.argtypes = [C.c_void_p, P(C.c_int32)]
+    try:
+        L.rt_result_pass_retries.argtypes = [C.c_void_p, P(C.c_int32)]
+    except AttributeError:
+        if not os.environ.get("RT_LIB"):
+            raise
     L.rt_result_table.argtypes = [C.c_void_p, P(C.c_double)]
     L.rt_result_step_counts.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
     L.rt_result_num_records.argtypes = [C.c_void_p, P(C.c_int64)]

@@ -552,6 +552,12 @@ __global__ void __launch_bounds__(BLOCK) k_level_compact(const KArgs a) {
 
 // rt_trace_device_noalloc: the "nothing scattered" rule of python/RayTracer2.py:405-407 (a step in which no ray scatters
 // tallies nothing), which run_trace() applies on the host, applied to the caller's device table; one block per step
+// tallies of a pass that has ended well, into the run's (run_trace: passes that may have to be repeated)
+__global__ void __launch_bounds__(BLOCK) k_table_add(double* table, const double* pass_table, int64_t n, unsigned long long* steps, const unsigned long long* pass_steps, int64_t m) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) { const double v = pass_table[i]; if (v != 0.0) atomicAdd(&table[i], v); }
+    else if (i < n + m) { const unsigned long long c = pass_steps[i - n]; if (c) atomicAdd(&steps[i - n], c); }
+}
 __global__ void __launch_bounds__(BLOCK) k_level_finish(double* table, const unsigned long long* n_scat, int row_elems) {
     if (n_scat[blockIdx.x] != 0ull) return;
     double* row = table + (size_t)blockIdx.x * row_elems;
@@ -913,6 +919,7 @@ struct rt_ctx {
     double ms_kind[3] = { 0, 0, 0 }; int n_kind[3] = { 0, 0, 0 }; // k_trace, k_level_hit, k_level_phys
     unsigned long long* d_lvl = nullptr; int lvl_K = 0;           // live rays per step of the level-synchronous path
     // options
+    int n_pass_retries = 0; // ray-splitting passes of the last trace that overflowed and were traced again in smaller ones (rt_result_pass_retries)
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
     int level_steps = 1 << 20; int64_t level_min_rays = 3 << 18; /* 786 432: below, the persistent kernel is faster (profiles/r3_sweep.json) */ int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, hit_split_lanes = 12, seg_per_cu = 8; bool seg_auto = true; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
@@ -1189,7 +1196,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
     size_t telems = (size_t)K * 5 * S * 2;
     if (!ctx->d_table_ext && prepare_tallies(ctx, K)) return -1; // (a lane: its parent has done this before the lanes started)
     double* const d_table = ctx->d_table_ext ? ctx->d_table_ext : ctx->d_table; unsigned long long* const d_steps = ctx->d_table_ext ? ctx->d_steps_ext : ctx->d_steps;
-    ctx->K = K; ctx->n_rays = n; ctx->kernel_ms = 0; ctx->n_launches = 0;
+    ctx->K = K; ctx->n_rays = n; ctx->kernel_ms = 0; ctx->n_launches = 0; ctx->n_pass_retries = 0;
     for (int i = 0; i < 3; i++) { ctx->ms_kind[i] = 0; ctx->n_kind[i] = 0; }
     // level-synchronous path: single-child runs with at most one child per ray and step
     const bool level = ctx->level_steps > 0 && (!single || !(prm->follow_threshold[1] < 0));
@@ -1355,8 +1362,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 
     hipEvent_t ev0 = ctx->ev[0], ev1 = ctx->ev[1], ev2 = ctx->ev[2];
     int rc = 0;
-    for (int64_t off = 0; off < n && rc == 0; off += chunk) {
-        int64_t m = std::min<int64_t>(chunk, n - off);
+    auto do_pass = [&](const int64_t off, const int64_t m) -> int {
+        int rc = 0;
         CK(hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
         a.mode = mode; a.n_in = m; a.ray_id_base = prm->ray_id_base + off * stride; a.slot_base = a.ray_id_base;
         if (fin_dev) a.fin = ctx->d_fin_user + (size_t)off * FIN;
@@ -1460,7 +1467,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 if (ovf) { ctx->err = ovf == 1 ? "rt_trace: record buffer overflow (raise workspace or lower nodice_chunk)" : "rt_trace: ray queue overflow (lower nodice_chunk)"; rc = -3; break; }
                 live = (int64_t)nxt; k0 += nb;
             }
-            if (rc) break;
+            if (rc) return rc;
             if (go && live > 0 && k0 < K) { // hand-over: the persistent kernel reads a dense queue
                 a.seg_in = seg[sin]; a.out = q[cur]; a.tail = ctx->d_counters + 1; a.step = k0; a.lean_hash = lean_hash_of(k0);
                 hipLaunchKernelGGL(k_level_compact, dim3((unsigned)nseg), dim3(BLOCK), 0, ctx->stream, a);
@@ -1469,7 +1476,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 a.in_d = q[cur].d; a.in_i = q[cur].i; a.in_m = q[cur].m; a.in_stride = q[cur].cap;
                 cur ^= 1;
             }
-            if (rc) break;
+            if (rc) return rc;
             a.n_in = live; a.tail = ctx->d_counters + 1;
         }
         // persistent kernel: everything (ray-splitting runs, one launch per generation) or the tail of a level-synchronous run
@@ -1495,7 +1502,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             cur ^= 1;
             CK(hipMemsetAsync(ctx->d_counters, 0, 16, ctx->stream)); // head, tail (records keep counting)
         }
-        if (rc) break;
+        if (rc) return rc;
         if (piped) {
             unsigned long long nrec = 0;
             CK(hipMemcpyAsync(&nrec, ctx->d_counters + 2, 8, hipMemcpyDeviceToHost, ctx->stream)); CK(hipStreamSynchronize(ctx->stream));
@@ -1511,7 +1518,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 stg[s].nrec = (int64_t)nrec; stg[s].first = prm->ray_id_base + off * stride; stg[s].m = m; stg[s].pending = true;
             }
             rc = drain(s ^ 1); // the previous chunk goes to the sink while this one is copied; the next one is traced under the same copy
-            if (rc) break;
+            if (rc) return rc;
         } else if (full) {
             unsigned long long nrec = 0;
             CK(hipMemcpy(&nrec, ctx->d_counters + 2, 8, hipMemcpyDeviceToHost));
@@ -1520,7 +1527,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 size_t base = ctx->rec_step.size();
                 DevBuf rows; CK(dev_alloc(ctx, rows, (size_t)REC * 8 * nrec));
                 hipLaunchKernelGGL(k_rec_to_rows, dim3((unsigned)((nrec * REC + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)b_rec.p, rec_cap, (int64_t)nrec, (double*)rows.p);
-                if (!ctx->rec.resize((base + nrec) * REC)) { ctx->err = "rt_trace: out of host memory for the records"; rc = -1; break; }
+                if (!ctx->rec.resize((base + nrec) * REC)) { ctx->err = "rt_trace: out of host memory for the records"; return -1; }
                 ctx->rec_step.resize(base + nrec); ctx->rec_flags.resize(base + nrec); ctx->rec_ray.resize(base + nrec); ctx->rec_parent.resize(base + nrec);
                 CK(hipMemcpyAsync(ctx->rec.data() + base * REC, rows.p, (size_t)REC * 8 * nrec, hipMemcpyDeviceToHost, ctx->stream));
                 CK(hipMemcpyAsync(ctx->rec_step.data() + base, b_rstep.p, 4 * nrec, hipMemcpyDeviceToHost, ctx->stream));
@@ -1533,12 +1540,40 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                     int src = ctx->sink(ctx->sink_user, (int64_t)nrec, ctx->rec.data(), ctx->rec_step.data(), ctx->rec_ray.data(), ctx->rec_parent.data(), ctx->rec_flags.data(),
                                         prm->ray_id_base + off * stride, m);
                     ctx->rec.clear(); ctx->rec_step.clear(); ctx->rec_flags.clear(); ctx->rec_ray.clear(); ctx->rec_parent.clear();
-                    if (src != 0) { ctx->err = "rt_trace: the record sink asked to stop"; rc = -4; break; }
+                    if (src != 0) { ctx->err = "rt_trace: the record sink asked to stop"; return -4; }
                 }
             }
         }
         if (wantfin && !fin_dev) CK(hipMemcpy(ctx->fin.data() + (size_t)off * FIN, b_fin.p, (size_t)FIN * 8 * (size_t)m, hipMemcpyDeviceToHost));
+        return rc;
+    };
+    // Passes.  A ray-splitting pass cannot bound its queues and records in advance; one that overflows is traced again in
+    // smaller passes from where it began, instead of failing the call and having the caller start over from ray 0: such a
+    // pass tallies into a table of its own, which is added to the run's (this context's, or the one the lanes share) when
+    // the pass has ended well and dropped when it has not - nothing else of a failed pass has left the device.
+    const bool can_retry = !single && !piped;
+    DevBuf b_ptab; double* p_table = nullptr; unsigned long long* p_steps = nullptr;
+    if (can_retry) { CK(dev_alloc(ctx, b_ptab, telems * 8 + sizeof(unsigned long long) * 2 * (size_t)K)); p_table = (double*)b_ptab.p; p_steps = (unsigned long long*)((char*)b_ptab.p + telems * 8); }
+    int shrunk = 0;
+    for (int64_t off = 0; off < n && rc == 0;) {
+        const int64_t m = std::min<int64_t>(chunk, n - off);
+        if (can_retry) {
+            CK(hipMemsetAsync(b_ptab.p, 0, telems * 8 + sizeof(unsigned long long) * 2 * (size_t)K, ctx->stream));
+            a.table = p_table; a.n_live = p_steps; a.n_scat = p_steps + K;
+        }
+        rc = do_pass(off, m);
+        if (rc == 0 && can_retry) {
+            hipLaunchKernelGGL(k_table_add, dim3((unsigned)((telems + 2 * (size_t)K + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, d_table, (const double*)p_table, (int64_t)telems, d_steps, (const unsigned long long*)p_steps, (int64_t)(2 * K));
+            CK(hipGetLastError());
+        }
+        if (rc == -3 && can_retry && shrunk < 8 && m > 256) {
+            CK(hipStreamSynchronize(ctx->stream));
+            chunk = std::max<int64_t>(256, m / 4); shrunk++; rc = 0; ctx->err.clear(); ctx->n_pass_retries++;
+            continue;
+        }
+        off += m;
     }
+    if (can_retry) CK(hipStreamSynchronize(ctx->stream)); // (the pass table goes back to the pool: the last addition has ended)
     if (piped) {
         for (int s = 0; s < 2 && rc == 0; s++) { const int t = (int)(((n + chunk - 1) / chunk + s) & 1); rc = drain(t); } // older stage first
         hipStreamSynchronize(ctx->copy_stream); // nothing of this call is in flight when its buffers go back to the pool
@@ -1559,6 +1594,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
 // are keyed by ray id, so the split changes no result.  Tally-only and device-final-row runs only, dice or ray splitting.
 static int run_trace_lanes(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm) {
     const bool full = prm->flags & RT_FLAG_FULL_OUTPUT, single = prm->flags & RT_FLAG_SINGLECHILD, wantfin = prm->flags & RT_FLAG_FINAL_ROWS;
+    for (auto* l : ctx->lane) if (l) l->n_pass_retries = 0;
     const bool eligible = ctx->lanes >= 2 && !ctx->is_lane && (mode == 0 || mode == 2) && !full && // (ray-splitting runs as well: 6.56e9 -> 7.50e9 interactions/s on the arbc_nodice workload)
                           !(prm->follow_threshold[1] < 0) && (!wantfin || ctx->d_fin_user) &&
                           ctx->level_steps > 0 && n >= ctx->lanes_min_rays && !ctx->sink && ctx->d_surf && prm->max_scatters >= 1 && prm->max_scatters <= 4094;
@@ -1821,6 +1857,7 @@ extern "C" int rt_debug_profile(rt_ctx* ctx, unsigned long long* out8, int reset
     return 0;
 }
 extern "C" int rt_result_num_steps(rt_ctx* ctx, int32_t* num_steps) { *num_steps = ctx->num_steps; return 0; }
+extern "C" int rt_result_pass_retries(rt_ctx* ctx, int32_t* n) { int t = ctx->n_pass_retries; for (auto* l : ctx->lane) if (l) t += l->n_pass_retries; *n = t; return 0; }
 extern "C" int rt_result_table(rt_ctx* ctx, double* table) { memcpy(table, ctx->table.data(), sizeof(double) * (size_t)ctx->num_steps * 5 * ctx->S * 2); return 0; }
 extern "C" int rt_result_table_device(rt_ctx* ctx, double* d_table, uint64_t* d_step_counts) {
     if (!d_table || ctx->K < 1 || !ctx->d_table) { ctx->err = "rt_result_table_device: no trace to report, or no destination"; return -1; }

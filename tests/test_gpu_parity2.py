@@ -103,6 +103,26 @@ def test_nodice_small_queue_retries():
     assert [len(r.ray_index) for r in b[0]] == [100000, 139957, 138120, 124864, 127220, 35043]
 
 
+def test_nodice_overflowing_pass_is_repeated_inside_the_call():
+    """a ray-splitting pass whose record buffer overflows (a workspace of 20 MB holds 65 536 records, a pass of 30 000 rays
+    makes 200 000) is traced again in smaller passes from where it began, by the library (include/rt_mi355x.h,
+    rt_result_pass_retries): same records and tallies as the run with room for everything, and no retry from ray 0"""
+    import ctypes as C
+    from raytracer_amd.RayTracer2 import Context, RayTracer2
+    sp, rays = cases.isotropic_rays(100000, 0, origin=(3, 0, 0))
+    args = ([10], [1e-9], np.array([1e-6, 1e-6]), [], True, False, False)
+    a = RayTracer2(sp, rays.copy(), cases.sphere_plane(), *args, seed=5)
+    c = Context(0); c.set_option("nodice_chunk", 30000); c.set_option("workspace_gb", 0.02)
+    try:
+        b = RayTracer2(sp, rays.copy(), cases.sphere_plane(), *args, seed=5, ctx=c)
+        n = C.c_int32(); c._check(c.L.rt_result_pass_retries(c.h, C.byref(n)))
+    finally:
+        c.close()
+    assert n.value >= 1, n.value
+    assert [len(r.ray_index) for r in a[0]] == [len(r.ray_index) for r in b[0]]
+    compare_results(types.SimpleNamespace(ray_interfaces=list(a[0]), absorption_table=a[1]), types.SimpleNamespace(ray_interfaces=list(b[0]), absorption_table=b[1]), tol=1e-12)
+
+
 def test_point_source_generation_and_trace():
     import ctypes as C
     from raytracer_amd import _lib
