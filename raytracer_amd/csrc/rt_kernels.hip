@@ -921,7 +921,7 @@ struct rt_ctx {
     // options
     int n_pass_retries = 0; // ray-splitting passes of the last trace that overflowed and were traced again in smaller ones (rt_result_pass_retries)
     size_t workspace_bytes = (size_t)32 << 30; int64_t nodice_chunk = 1 << 20; int refill_min = 4; int blocks_per_cu = 0; size_t lds_budget = 32 * 1024;
-    int level_steps = 1 << 20; int64_t level_min_rays = 3 << 18; /* 786 432: below, the persistent kernel is faster (profiles/r3_sweep.json) */ int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, hit_split_lanes = 12, seg_per_cu = 8; bool seg_auto = true; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
+    int level_steps = 1 << 20; int64_t level_min_rays = -1; /* below that many live rays the persistent kernel takes over; -1: by run mode, see level_min_rays_of() */ int hit_blocks_per_cu = 0, phys_blocks_per_cu = 0, hit_split = 128, hit_split_lanes = 12, seg_per_cu = 8; bool seg_auto = true; int sync_every = 8; int64_t sync_rays_max = (int64_t)1 << 24;
     int match_max_level = 10; // rt_match_endpoints: deepest octree level (0: one uniform grid of cell size max_dist)
     // further lanes of large tally-only runs (run_trace_lanes; two by default): contexts of their own that borrow this one's
     // geometry.  The launches of the lanes overlap - which is what they are for - so per-kernel times then include the company
@@ -977,7 +977,7 @@ extern "C" int rt_init(int device, rt_ctx** out) {
     const char* nc = getenv("RT_NODICE_CHUNK"); if (nc && atoll(nc) > 0) ctx->nodice_chunk = atoll(nc);
     const char* nf = getenv("RT_NO_FRAMES"); if (nf && atoi(nf) > 0) ctx->use_frames = false;
     const char* ls = getenv("RT_LEVEL_STEPS"); if (ls && atoi(ls) >= 0) ctx->level_steps = atoi(ls);
-    const char* lm = getenv("RT_LEVEL_MIN_RAYS"); if (lm && atoll(lm) >= 0) ctx->level_min_rays = atoll(lm);
+    const char* lm = getenv("RT_LEVEL_MIN_RAYS"); if (lm) ctx->level_min_rays = atoll(lm) >= 0 ? atoll(lm) : -1;
     const char* hs = getenv("RT_HIT_SPLIT"); if (hs && atoi(hs) > 0) ctx->hit_split = atoi(hs);
     const char* ln = getenv("RT_LANES"); if (ln && atoi(ln) >= 1 && atoi(ln) <= 4) ctx->lanes = atoi(ln);
     const char* la = getenv("RT_LANES_ALTERNATE"); if (la) ctx->lanes_alternate = atoi(la) != 0;
@@ -1034,7 +1034,7 @@ extern "C" int rt_set_option(rt_ctx* ctx, const char* key, double value) {
     else if (k == "stream_stage_gb") { if (!(value > 0)) { ctx->err = "rt_set_option: stream_stage_gb must be positive"; return -1; } ctx->stream_stage_bytes = (size_t)(value * (double)(1ull << 30)); }
     else if (k == "frames") ctx->use_frames = value != 0;
     else if (k == "level_steps") ctx->level_steps = (int)value;
-    else if (k == "level_min_rays") ctx->level_min_rays = (int64_t)value;
+    else if (k == "level_min_rays") ctx->level_min_rays = value >= 0 ? (int64_t)value : -1; // (negative: back to the defaults by run mode)
     else if (k == "hit_blocks_per_cu") ctx->hit_blocks_per_cu = (int)value;
     else if (k == "hit_split") ctx->hit_split = (int)value;
     else if (k == "hit_split_lanes") ctx->hit_split_lanes = std::max(1, (int)value);
@@ -1178,6 +1178,16 @@ int fetch_tallies(rt_ctx* ctx, int K) {
     return 0;
 }
 
+// Live rays below which the persistent kernel is faster than the level-synchronous pair, by run mode (one lane, jar geometry,
+// profiles/r3_level_threshold.txt): tally-only single-child runs have the lean persistent instances (2 waves per SIMD, whole
+// register file): 786 432; single-child runs that keep final rows: 262 144 (their persistent instance holds three rays'
+// worth of state and spills); with records the host's share decides and the persistent kernel stays ahead at every size
+// measured: 786 432; ray-splitting runs: 0 - the level path is 2 to 4.5 times faster from 256 rays up.
+static int64_t level_min_rays_of(const rt_ctx* ctx, bool single, bool full, bool wantfin) {
+    if (ctx->level_min_rays >= 0) return ctx->level_min_rays;
+    if (!single) return 0;
+    return (wantfin && !full) ? ((int64_t)1 << 18) : ((int64_t)3 << 18);
+}
 // mode 0: h_start/h_rays host arrays or d_soa device SoA; mode 2: point source
 int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm, int64_t soa_stride = 0) {
     if (!ctx->d_surf) { ctx->err = "rt_trace: no surfaces set"; return -1; }
@@ -1407,7 +1417,8 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
             CK(hipMemsetAsync(ctx->d_lvl, 0, sizeof(unsigned long long) * ((size_t)K + 2), ctx->stream));
             CK(hipMemsetAsync(b_seg.p, 0, sizeof(uint32_t) * 2 * (size_t)nseg_max, ctx->stream));
             a.seg_cap = seg_cap; ha.seg_cap = seg_cap;
-            const bool go = K > 0 && ctx->level_steps > 0 && live >= ctx->level_min_rays;
+            const int64_t lmin = level_min_rays_of(ctx, single, full, wantfin);
+            const bool go = K > 0 && ctx->level_steps > 0 && live >= lmin;
             if (go) { // initial rays -> queue 1 (step 0 writes queue 0)
                 a.out = q[1]; a.seg_out = seg[1];
                 hipLaunchKernelGGL(kinit, dim3((unsigned)((live + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, a);
@@ -1415,7 +1426,7 @@ int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays
                 a.mode = 1; a.in_d = q[1].d; a.in_i = q[1].i; a.in_m = q[1].m; a.in_stride = q[1].cap;
             }
             int sin = 1; // seg[sin]: counts of the input queue
-            while (k0 < K && k0 < ctx->level_steps && live > 0 && live >= ctx->level_min_rays) {
+            while (k0 < K && k0 < ctx->level_steps && live > 0 && live >= lmin) {
                 // The host learns the live count by waiting for the step (the kernels themselves read the counts of their
                 // segments from device memory).  Runs whose steps take milliseconds wait after every step; on smaller ones
                 // the round trip is a tenth to a third of the step (profiles/r2_sweep.json), so `sync_every` steps are
