@@ -194,7 +194,7 @@ int rt_generate_camera_rays(rt_ctx* ctx, const rt_camera* cam, int64_t first, in
 /* Tuning knobs (no reference counterpart): "workspace_gb" (device memory for records/queues, default 32),
  * "level_steps" / "level_min_rays" (runs are traced step by step for at most that many steps and while
  * at least that many rays are live, the persistent kernel takes the rest; no cap / by run mode: 786432 for single-child
- * runs that keep tallies only or records, 32768 for those that keep final rows, 0 for ray-splitting runs - a negative
+ * runs that keep tallies only or records, 524288 for those that keep final rows, 0 for ray-splitting runs - a negative
  * value restores these), "defer_unified" (0: rays ending
  * on UNIFIED surfaces are not given a physics launch of their own), "hit_split" / "hit_split_lanes" (blocks of the nearest-hit
  * launch per queue segment: alone on the GPU, default 128 = one per tile of 256 rays; beside another lane's physics launches, default 12), "seg_per_cu" (queue segments per CU; default

@@ -330,7 +330,7 @@ __device__ __noinline__ Hit find_hit_ool(V3 sp, V3 d, int six_last, bool act) { 
 } // namespace rt
 namespace {
 #ifndef RT_WAVES
-#define RT_WAVES 4
+#define RT_WAVES 2 /* the instances that keep records or final rows, or split rays: the whole register file as well (at 4 waves per SIMD they spilled 488-746 VGPRs: runs with final rows 1.5 to 2 times slower, profiles/r3_level_threshold.txt) */
 #endif
 #ifndef RT_LEAN_TRACE_WAVES
 #define RT_LEAN_TRACE_WAVES 2
@@ -1180,15 +1180,15 @@ int fetch_tallies(rt_ctx* ctx, int K) {
 
 // Live rays below which the persistent kernel is faster than the level-synchronous pair, by run mode (one lane, jar geometry,
 // profiles/r3_level_threshold.txt): tally-only single-child runs have the lean persistent instances (2 waves per SIMD, whole
-// register file): 786 432; single-child runs that keep final rows: 32 768 as in round 2 (long chains - the jar with
-// reflective cones, K = 100 - cross at ~250 k, but what keeps final rows is the image pipeline, whose chains are three
-// interactions long: tools/bench_image.py is 3-7 % faster with 32 768 than with 262 144 at 65 k to 250 k pixels); with
+// register file): 786 432; single-child runs that keep final rows: 524 288 (long chains - the jar with reflective cones,
+// K = 100 - cross there; the image pipeline, whose chains are three interactions long, is level or a little faster on the
+// persistent kernel up to 500 k pixels, tools/bench_image.py); with
 // records the host's share decides and the persistent kernel stays ahead at every size
 // measured: 786 432; ray-splitting runs: 0 - the level path is 2 to 4.5 times faster from 256 rays up.
 static int64_t level_min_rays_of(const rt_ctx* ctx, bool single, bool full, bool wantfin) {
     if (ctx->level_min_rays >= 0) return ctx->level_min_rays;
     if (!single) return 0;
-    return (wantfin && !full) ? ((int64_t)1 << 15) : ((int64_t)3 << 18);
+    return (wantfin && !full) ? ((int64_t)1 << 19) : ((int64_t)3 << 18);
 }
 // mode 0: h_start/h_rays host arrays or d_soa device SoA; mode 2: point source
 int run_trace(rt_ctx* ctx, int mode, const double* h_start, const double* h_rays, const double* d_soa, const double* origin, int64_t n, const rt_params* prm, int64_t soa_stride = 0) {
