@@ -598,7 +598,10 @@ template <bool GENERIC> __global__ void __launch_bounds__(BLOCK, GENERIC ? RT_HI
 // PASS 2: the listed rays, children appended behind those of pass 1; for CF == FLAG_SINGLE (tallies only) the wave
 // works through the UNIFIED model together (unified_wave), otherwise every lane runs it in line.
 // PASS 3: PASS 0 for a geometry without UNIFIED surfaces (no such code in the kernel).
-#define RT_PHYS_BOUNDS(CF, PASS) (PASS == 2 ? RT_UNI_WAVES : (CF == FLAG_SINGLE ? RT_LEAN_WAVES : (PASS == 1 ? RT_P1_WAVES : RT_PHYS_WAVES)))
+#ifndef RT_OUT_WAVES
+#define RT_OUT_WAVES 2 /* the physics launches that write records or final rows: at 3 waves per SIMD they spill 16-155 VGPRs, at 2 none to 49 (image pipeline -4 % at 33.5 M pixels, -6 % at 4 M; record streaming unchanged) */
+#endif
+#define RT_PHYS_BOUNDS(CF, PASS) (PASS == 2 ? RT_UNI_WAVES : (CF == FLAG_SINGLE ? RT_LEAN_WAVES : ((CF & (FLAG_FULL | FLAG_FINAL)) ? RT_OUT_WAVES : (PASS == 1 ? RT_P1_WAVES : RT_PHYS_WAVES))))
 template <int CF, int PASS = 0> __global__ void __launch_bounds__(BLOCK, RT_PHYS_BOUNDS(CF, PASS)) k_level_phys(const KArgs a) {
     extern __shared__ double smem[];
 #ifdef RT_PROFILE
